@@ -1,0 +1,208 @@
+/*
+ * skyeye_hip.h -- C ABI of libskyeye_hip.so, the MI355X (gfx950) inference engine for the
+ * SkyEye detection forward pass.
+ *
+ * The reference (UmaimaKhan01/SkyEye-Aerial-Object-Detection-using-Yolo) has no FFI: its boundary is the
+ * Python class API of skyeye/core/models/detector.py.  Each entry point below therefore cites the Python
+ * interface it stands in for; the ctypes shim in
+ * skyeye-aerial-object-detection-using-yolo_amd/skyeye/_native.py binds exactly these symbols and
+ * presents the reference's classes on top of them.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative sky_status; nothing throws across the ABI;
+ *     sky_last_error(h) gives the text for the last failure on that handle (sky_last_error(NULL) for
+ *     failures of sky_create itself)
+ *   - the caller owns every input / output buffer; the engine owns weights and its workspace arena
+ *   - device pointers are plain HIP device pointers (e.g. torch.Tensor.data_ptr()); `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream)
+ *   - one handle per (device, stream); a handle is not thread-safe, different handles are independent
+ *   - all kernels are launched asynchronously on `stream`; the only host synchronisation is inside
+ *     sky_nms_fetch (it returns counts to the host)
+ */
+#ifndef SKYEYE_HIP_H
+#define SKYEYE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKY_ABI_VERSION 1
+#define SKY_MAX_LEVELS 4
+#define SKY_MAX_ANCHORS 8
+#define SKY_MAX_IO 4
+
+typedef enum {
+    SKY_OK = 0,
+    SKY_ERR_INVALID = -1,       /* bad argument / unsupported configuration */
+    SKY_ERR_MISSING_WEIGHT = -2,
+    SKY_ERR_SHAPE = -3,
+    SKY_ERR_HIP = -4,           /* a HIP runtime call failed */
+    SKY_ERR_STATE = -5,         /* call order violated (forward before plan, ...) */
+    SKY_ERR_NO_DEVICE = -6
+} sky_status;
+
+/* arithmetic type of the activations / MFMA operands (accumulation is always fp32) */
+typedef enum {
+    SKY_F32 = 0,   /* exact mode: v_mfma_f32_16x16x4_f32, used for the 1e-4 parity gate */
+    SKY_BF16 = 1   /* production mode: v_mfma_f32_16x16x32_bf16 */
+} sky_dtype;
+
+/* element type / layout of caller buffers at the boundary */
+typedef enum { SKY_IO_F32 = 0, SKY_IO_U8 = 1 } sky_io_dtype;
+typedef enum { SKY_NCHW = 0, SKY_NHWC = 1 } sky_layout;
+
+/* Which reference module a handle implements.  Values name the reference class (file:line). */
+typedef enum {
+    SKY_MOD_DETECTOR = 0,          /* SkyEyeDetector           detector.py:234-371 (with SURVEY D1/D2/D3)      */
+    SKY_MOD_ENHANCED_DETECTOR = 1, /* EnhancedSkyEyeDetector   detector.py:436-501 (with D4)                   */
+    SKY_MOD_CONV_BLOCK = 2,        /* ConvolutionBlock         blocks.py:10-41                                */
+    SKY_MOD_BOTTLENECK = 3,        /* BottleneckBlock          blocks.py:69-90                                */
+    SKY_MOD_CSP = 4,               /* CSPBlock                 blocks.py:93-123                               */
+    SKY_MOD_SPP = 5,               /* SPPBlock                 blocks.py:126-149                              */
+    SKY_MOD_FOCUS = 6,             /* FocusBlock               blocks.py:152-182                              */
+    SKY_MOD_CHANNEL_ATTENTION = 7, /* ChannelAttention         attention.py:11-60                             */
+    SKY_MOD_SPATIAL_ATTENTION = 8, /* SpatialAttention         attention.py:63-98                             */
+    SKY_MOD_COMBINED_ATTENTION = 9,/* CombinedAttention        attention.py:101-130                           */
+    SKY_MOD_BACKBONE = 10,         /* Backbone / CSPDarknet    backbone.py:12-116                             */
+    SKY_MOD_NECK = 11,             /* FeatureNeck              detector.py:148-231                            */
+    SKY_MOD_HEAD = 12,             /* DetectionHead (+process_detections) detector.py:18-145                  */
+    SKY_MOD_CROSS_LAYER_ATTENTION = 13, /* CrossLayerAttention attention.py:133-241                           */
+    SKY_MOD_TRANSFORMER_LAYER = 14,     /* TransformerLayer    attention.py:244-309                           */
+    SKY_MOD_WINDOWED_ATTENTION = 15,    /* WindowedSelfAttention attention.py:312-399                         */
+    SKY_MOD_DECODE = 16,           /* DetectionHead.process_detections alone  detector.py:88-145 (inputs: raw levels) */
+    SKY_MOD_UTILITY = 100          /* no graph: a handle that only carries the NMS workspace (metrics.py:361-457)  */
+} sky_module;
+
+/*
+ * Constructor arguments.  Field names follow the reference's keyword arguments / YAML keys
+ * (detector.py:255-285,393-405: nc, base_channels, depth_multiple, width_multiple, anchors).
+ * Unused fields for a given module are ignored.
+ */
+typedef struct {
+    uint32_t struct_size;       /* sizeof(sky_config), for ABI checking */
+    int32_t module;             /* sky_module */
+    int32_t dtype;              /* sky_dtype */
+    int32_t device;             /* HIP device ordinal */
+    /* detector / backbone */
+    int32_t base_channels;      /* default 64 */
+    float depth_multiple;       /* default 1.0 */
+    float width_multiple;       /* default 1.0 */
+    int32_t nc;                 /* number of classes */
+    int32_t in_channels;        /* image channels (3) */
+    int32_t num_levels;         /* detection levels (3) */
+    int32_t num_anchors;        /* anchors per level (3) */
+    float anchors[SKY_MAX_LEVELS * SKY_MAX_ANCHORS * 2]; /* [level][anchor][w,h], pixels */
+    /* generic block arguments */
+    int32_t c_in, c_out;        /* in_channels / out_channels (dim for attention / transformer) */
+    int32_t kernel_size, stride;
+    int32_t activation;         /* ConvolutionBlock(activation=) */
+    int32_t num_blocks;         /* CSPBlock(num_blocks=) */
+    int32_t shortcut;           /* BottleneckBlock(shortcut=) */
+    float expansion;            /* BottleneckBlock / CSPBlock expansion */
+    int32_t heads;              /* attention heads */
+    int32_t window_size;        /* WindowedSelfAttention */
+    int32_t region_size;        /* CrossLayerAttention */
+    int32_t reduction_ratio;    /* ChannelAttention (16) */
+    int32_t key_channels;       /* CrossLayerAttention key/value input channels (D4 when != c_in) */
+    int32_t level_channels[SKY_MAX_LEVELS]; /* FeatureNeck in_channels / DetectionHead channels */
+    int32_t input_h, input_w;   /* DetectionHead.process_detections(outputs, input_shape) for a standalone head */
+    int32_t reserved[6];
+} sky_config;
+
+/* One named host fp32 tensor of a state dict (names as in SURVEY Appendix C, relative to the module). */
+typedef struct {
+    const char* name;
+    const void* data;           /* host pointer, fp32 (int64 entries such as num_batches_tracked are skipped) */
+    int32_t ndim;
+    int64_t shape[4];
+} sky_tensor_desc;
+
+/* A caller buffer handed to sky_forward. */
+typedef struct {
+    void* data;                 /* device pointer */
+    int32_t dtype;              /* sky_io_dtype */
+    int32_t layout;             /* sky_layout (ignored for rank-3 token tensors) */
+    int32_t ndim;
+    int64_t shape[5];
+} sky_buffer;
+
+/* Arguments of the reference's non_max_suppression (metrics.py:361-369) + the build's semantics switch. */
+typedef struct {
+    uint32_t struct_size;
+    float conf_threshold;       /* 0.25 */
+    float iou_threshold;        /* 0.45 */
+    int32_t agnostic;
+    int32_t multi_label;
+    int32_t max_detections;     /* 300 */
+    int32_t max_nms;            /* 30000, metrics.py:393 */
+    float max_wh;               /* 4096, metrics.py:392 */
+    int32_t mode;               /* 0 = literal (file as written, D7-D9), 1 = corrected (YOLOv5 semantics) */
+    int32_t n_classes;          /* length of `classes`, 0 = no filter */
+    int32_t classes[64];
+} sky_nms_params;
+
+typedef struct sky_handle sky_handle;
+
+/* Library / device probes (no compute). */
+int sky_abi_version(void);
+int sky_device_count(void);
+const char* sky_last_error(const sky_handle* h);
+
+/* SkyEyeDetector.__init__ / construct_model (detector.py:239-298, :409-433) and the block constructors. */
+int sky_create(const sky_config* cfg, sky_handle** out);
+void sky_destroy(sky_handle* h);
+
+/* Number / names / shapes of the state-dict entries this module expects (nn.Module.state_dict()). */
+int sky_num_params(const sky_handle* h);
+int sky_param_info(const sky_handle* h, int index, const char** name, int32_t* ndim, int64_t shape[4]);
+
+/* load_state_dict / load_from_pretrained (detector.py:343-371): copies, folds BN, converts dtype+layout. */
+int sky_load_weights(sky_handle* h, const sky_tensor_desc* descs, int n);
+
+/* Fix the input geometry (the reference is shape-polymorphic; the engine plans a static graph per shape). */
+int sky_plan(sky_handle* h, int n_inputs, const sky_buffer* input_shapes);
+
+/* Output shapes of the planned graph, in forward() order. */
+int sky_num_outputs(const sky_handle* h);
+int sky_output_info(const sky_handle* h, int index, int32_t* ndim, int64_t shape[5]);
+
+/* nn.Module.forward (detector.py:300-324 for the detector: outputs = [detections, raw_P3, raw_P4, raw_P5]). */
+int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs,
+                void* stream);
+
+/*
+ * non_max_suppression (metrics.py:361-457) on device.
+ *   det   [B, N, nc+5] fp32 device
+ *   out   [B, max_detections, 7] fp32 device (rows packed at stride 7; literal mode with nc>1 fills 7
+ *         columns, every other case 6)
+ *   counts[B] int32 device
+ * sky_nms is asynchronous; sky_nms_fetch copies counts to the host (synchronises the stream).
+ */
+int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms_params* p, float* out,
+            int32_t* counts, void* stream);
+int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream);
+
+/* Engine statistics for the bench harness: algorithmic FLOPs (2*MAC over conv/linear) and activation bytes
+ * of the planned graph, number of launches per forward. */
+int sky_plan_stats(const sky_handle* h, double* flops, double* activation_bytes, double* weight_bytes,
+                   int32_t* launches);
+
+/* Timing hooks used by bench.py: time `iters` back-to-back forwards with hipEvents on `stream`
+ * (events recorded on the stream the kernels are launched on). Returns mean milliseconds per forward. */
+int sky_time_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs,
+                     const sky_buffer* outputs, void* stream, int iters, float* ms_per_iter);
+
+/* Per-launch timing of the planned graph (bench.py's roofline leg): runs `iters` forwards with a hipEvent recorded
+ * on `stream` after every launch and returns, per launch, the mean milliseconds, the algorithmic FLOPs, and a tag
+ * (op kind * 1000 + N-tile of the convolution kernel variant, 0 for non-GEMM launches). */
+int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs,
+                        void* stream, int iters, int max_ops, float* ms_per_op, double* flops_per_op, int32_t* tag_per_op,
+                        int32_t* n_ops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKYEYE_HIP_H */

@@ -1,0 +1,1234 @@
+// libskyeye_hip.so -- graph planner, weight preparation and the C ABI (include/skyeye_hip.h).
+//
+// The engine mirrors the reference's module tree (blocks.py / attention.py / backbone.py / detector.py) as a set
+// of builder functions.  A builder run does two things at once: it records the state-dict entries the module
+// expects (names as in the reference) and -- when a geometry is given -- emits a static list
+// of fused kernel launches over one workspace arena:
+//   * ConvolutionBlock  -> one implicit-GEMM launch, BatchNorm folded into the packed weights, SiLU in the epilogue
+//   * CSPBlock          -> cv1 and cv2 share one GEMM (N = 2h) that writes the concat buffer; bottlenecks update
+//                          the first half in place; torch.cat never materialises
+//   * FeatureNeck       -> lateral convs write their output 2x-upsampled straight into the concat slice
+//   * SPPBlock          -> cascade of 5x5 max-pools writing concat slices
+//   * DetectionHead     -> 1x1 GEMM whose epilogue writes raw logits and decoded boxes
+// Buffers are placed in the arena by lifetime (first/last use), so the working set stays small enough for the
+// 256 MiB Infinity Cache to serve producer->consumer traffic at small batch.
+#include "../../include/skyeye_hip.h"
+#include "sky_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sky {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define SKY_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            throw Error(SKY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+static std::string g_create_error;
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t numel() const
+    {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct ParamSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+};
+
+// view of an activation tensor inside a workspace buffer (or a caller buffer when ext >= 0)
+struct TV {
+    int buf = -1;
+    long off = 0;   // element offset (channel offset inside the pixel)
+    int B = 0, H = 0, W = 0, C = 0, ld = 0;
+    int ext = -1;   // 0..15 input slot, 16.. output slot
+    bool valid() const { return buf >= 0 || ext >= 0; }
+};
+
+enum OpKind { OP_IMPORT, OP_EXPORT, OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE, OP_CA_REDUCE, OP_CA_MLP, OP_SA_STATS, OP_SA_GATE, OP_SCALE, OP_DECODE };
+
+struct Op {
+    OpKind kind;
+    TV in, out, res;
+    // conv
+    int wid = -1;          // index into Engine::convs
+    int cin = 0, cout = 0, ks = 1, stride = 1, act = 0, up2 = 0;
+    int head = 0, level = 0;
+    int raw_ext = -1, det_ext = -1;
+    long det_rows = 0, det_off = 0;
+    float stride_px = 0;
+    // import
+    int s2d = 0, src_c = 0, src_h = 0, src_w = 0;
+    // scratch buffers (fp32), buffer ids
+    int s0 = -1, s1 = -1, s2 = -1;
+    int nchunk = 0, R = 0;
+    int f0 = -1, f1 = -1;  // fp32 device weights (index into Engine::fweights)
+    int Ho = 0, Wo = 0;
+    double flops = 0;
+};
+
+struct DevConv {
+    void* w = nullptr;
+    float* bias = nullptr;
+    int Kpad = 0;
+    size_t bytes = 0;
+};
+
+struct Buffer {
+    size_t bytes = 0;
+    int first = 1 << 30, last = -1;
+    size_t offset = 0;
+};
+
+struct IoInfo {
+    int ndim = 0;
+    int64_t shape[5] = {0, 0, 0, 0, 0};
+};
+
+struct Engine {
+    sky_config cfg;
+    int dtype = 0;
+    std::string err;
+    std::map<std::string, HostTensor> weights;
+    std::vector<ParamSpec> spec;
+    // plan
+    bool planned = false;
+    bool weights_dirty = true;
+    std::vector<Op> ops;
+    std::vector<Buffer> bufs;
+    std::vector<DevConv> convs;
+    std::vector<float*> fweights;
+    std::vector<void*> owned;   // device allocations to free on re-plan
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<IoInfo> in_info, out_info;
+    std::vector<sky_buffer> plan_inputs;
+    double flops = 0, act_bytes = 0, weight_bytes = 0;
+    // nms workspace
+    void* nms_ws = nullptr;
+    size_t nms_ws_bytes = 0;
+
+    int esize() const { return dtype == SKY_F32 ? 4 : 2; }
+    int epc() const { return dtype == SKY_F32 ? 4 : 8; }
+    void free_plan()
+    {
+        for (void* p : owned) (void)hipFree(p);
+        owned.clear();
+        if (arena) (void)hipFree(arena);
+        arena = nullptr;
+        arena_bytes = 0;
+        ops.clear();
+        bufs.clear();
+        convs.clear();
+        fweights.clear();
+        planned = false;
+    }
+    ~Engine()
+    {
+        free_plan();
+        if (nms_ws) (void)hipFree(nms_ws);
+    }
+};
+
+static unsigned short f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// ------------------------------------------------------------------------------------------------ builder context
+struct Ctx {
+    Engine& e;
+    bool emit;   // false: only collect the parameter spec
+    std::map<std::string, bool> seen;
+
+    explicit Ctx(Engine& eng, bool em) : e(eng), emit(em) {}
+
+    void need(const std::string& name, std::vector<int64_t> shape)
+    {
+        if (!seen.count(name)) {
+            seen[name] = true;
+            e.spec.push_back({name, shape});
+        }
+        if (emit) {
+            auto it = e.weights.find(name);
+            if (it == e.weights.end()) throw Error(SKY_ERR_MISSING_WEIGHT, "missing weight '" + name + "'");
+            if (it->second.shape != shape) {
+                std::string s = "shape mismatch for '" + name + "': expected [";
+                for (auto v : shape) s += std::to_string(v) + ",";
+                s += "] got [";
+                for (auto v : it->second.shape) s += std::to_string(v) + ",";
+                throw Error(SKY_ERR_SHAPE, s + "]");
+            }
+        }
+    }
+    const HostTensor& W(const std::string& name) { return e.weights.at(name); }
+
+    int new_buf(size_t bytes)
+    {
+        Buffer b;
+        b.bytes = (bytes + 255) / 256 * 256;
+        e.bufs.push_back(b);
+        return (int)e.bufs.size() - 1;
+    }
+    TV new_tensor(int B, int H, int W_, int C)
+    {
+        TV t;
+        t.B = B; t.H = H; t.W = W_; t.C = C; t.ld = C;
+        t.buf = emit ? new_buf((size_t)B * H * W_ * C * e.esize()) : 0;
+        return t;
+    }
+    static TV slice(const TV& t, int c0, int C)
+    {
+        TV s = t;
+        s.off = t.off + c0;
+        s.C = C;
+        return s;
+    }
+    void touch(int buf)
+    {
+        if (buf < 0) return;
+        Buffer& b = e.bufs[buf];
+        const int i = (int)e.ops.size();
+        b.first = std::min(b.first, i);
+        b.last = std::max(b.last, i);
+    }
+    void push(Op op)
+    {
+        if (!emit) return;
+        touch(op.in.buf); touch(op.out.buf); touch(op.res.buf);
+        touch(op.s0); touch(op.s1); touch(op.s2);
+        e.flops += op.flops;
+        e.ops.push_back(op);
+    }
+
+    void check_channels(int c, const char* what)
+    {
+        if (c <= 0 || c % e.epc() != 0)
+            throw Error(SKY_ERR_INVALID, std::string(what) + ": channel count " + std::to_string(c) +
+                                             " is not a multiple of " + std::to_string(e.epc()) + " (16-byte vectors)");
+    }
+
+    // upload helpers -------------------------------------------------------------------------------------
+    int upload_f32(const std::vector<float>& v)
+    {
+        if (!emit) return -1;
+        float* d = nullptr;
+        SKY_HIP(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(float)));
+        e.owned.push_back(d);
+        SKY_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        e.weight_bytes += v.size() * sizeof(float);
+        e.fweights.push_back(d);
+        return (int)e.fweights.size() - 1;
+    }
+
+    // Pack conv weights [Cout][taps*cin_store] (+BN fold) for one or two stacked convolutions.
+    struct ConvSrc {
+        std::string wname;   // conv weight
+        std::string bn;      // bn prefix ("" = none)
+        std::string bias;    // bias name ("" = none)
+    };
+    int pack_conv(const std::vector<ConvSrc>& srcs, int cin_real, int cin_store, int ks)
+    {
+        if (!emit) return -1;
+        int cout = 0;
+        for (auto& s : srcs) cout += (int)W(s.wname).shape[0];
+        const int taps = ks * ks;
+        const int kstep = conv_k_step(e.dtype);
+        const int K = taps * cin_store;
+        const int Kpad = (K + kstep - 1) / kstep * kstep;
+        const size_t rows = conv_weight_rows(cout);
+        std::vector<float> packed(rows * Kpad, 0.0f), bias(rows, 0.0f);
+        int row0 = 0;
+        for (auto& s : srcs) {
+            const HostTensor& w = W(s.wname);
+            const int co_n = (int)w.shape[0];
+            for (int co = 0; co < co_n; ++co) {
+                float scale = 1.0f, shift = 0.0f;
+                if (!s.bn.empty()) {
+                    // eval BatchNorm (eps 1e-5): y = (x - mean) / sqrt(var + eps) * gamma + beta
+                    const float g = W(s.bn + "weight").data[co], b = W(s.bn + "bias").data[co];
+                    const float mu = W(s.bn + "running_mean").data[co], var = W(s.bn + "running_var").data[co];
+                    scale = g / std::sqrt(var + 1e-5f);
+                    shift = b - mu * scale;
+                }
+                if (!s.bias.empty()) shift += W(s.bias).data[co] * scale;
+                bias[row0 + co] = shift;
+                float* dst = packed.data() + (size_t)(row0 + co) * Kpad;
+                for (int ci = 0; ci < cin_real; ++ci)
+                    for (int t = 0; t < taps; ++t)
+                        dst[t * cin_store + ci] = w.data[((size_t)co * cin_real + ci) * taps + t] * scale;
+            }
+            row0 += co_n;
+        }
+        DevConv d;
+        d.Kpad = Kpad;
+        d.bytes = packed.size() * e.esize();
+        SKY_HIP(hipMalloc(&d.w, d.bytes));
+        e.owned.push_back(d.w);
+        if (e.dtype == SKY_F32) {
+            SKY_HIP(hipMemcpy(d.w, packed.data(), d.bytes, hipMemcpyHostToDevice));
+        } else {
+            std::vector<unsigned short> h(packed.size());
+            for (size_t i = 0; i < packed.size(); ++i) h[i] = f32_to_bf16(packed[i]);
+            SKY_HIP(hipMemcpy(d.w, h.data(), d.bytes, hipMemcpyHostToDevice));
+        }
+        SKY_HIP(hipMalloc(&d.bias, rows * sizeof(float)));
+        e.owned.push_back(d.bias);
+        SKY_HIP(hipMemcpy(d.bias, bias.data(), rows * sizeof(float), hipMemcpyHostToDevice));
+        e.weight_bytes += d.bytes + rows * sizeof(float);
+        e.convs.push_back(d);
+        return (int)e.convs.size() - 1;
+    }
+};
+
+static int out_dim(int n, int k, int s) { return (n + 2 * (k / 2) - k) / s + 1; }
+
+static void need_bn(Ctx& c, const std::string& p, int ch)
+{
+    c.need(p + "weight", {ch});
+    c.need(p + "bias", {ch});
+    c.need(p + "running_mean", {ch});
+    c.need(p + "running_var", {ch});
+}
+
+struct ConvOpt {
+    const TV* out_into = nullptr;
+    const TV* res = nullptr;
+    bool up2 = false;
+    int cin_real = -1;   // when the stored tensor has zero-padded channels (stem)
+};
+
+// ConvolutionBlock (blocks.py:10-41)
+static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int k, int s, bool act, ConvOpt o = ConvOpt())
+{
+    const int cin_real = o.cin_real > 0 ? o.cin_real : cin;
+    if (k != 1 && k != 3) throw Error(SKY_ERR_INVALID, p + ": kernel_size " + std::to_string(k) + " not supported (1 or 3)");
+    c.need(p + "conv.weight", {cout, cin_real, k, k});
+    need_bn(c, p + "bn.", cout);
+    c.check_channels(cin, (p + "in_channels").c_str());
+    c.check_channels(cout, (p + "out_channels").c_str());
+    if (x.C != cin) throw Error(SKY_ERR_SHAPE, p + ": input has " + std::to_string(x.C) + " channels, expected " + std::to_string(cin));
+    const int Ho = out_dim(x.H, k, s), Wo = out_dim(x.W, k, s);
+    TV y;
+    if (o.out_into) {
+        y = *o.out_into;
+        const int eh = o.up2 ? 2 * Ho : Ho, ew = o.up2 ? 2 * Wo : Wo;
+        if (y.C != cout || y.H != eh || y.W != ew || y.B != x.B) throw Error(SKY_ERR_SHAPE, p + ": output slot geometry mismatch");
+    } else {
+        y = c.new_tensor(x.B, o.up2 ? 2 * Ho : Ho, o.up2 ? 2 * Wo : Wo, cout);
+    }
+    Op op;
+    op.kind = OP_CONV;
+    op.in = x; op.out = y;
+    if (o.res) op.res = *o.res;
+    op.cin = cin; op.cout = cout; op.ks = k; op.stride = s; op.act = act ? ACT_SILU : ACT_NONE; op.up2 = o.up2 ? 1 : 0;
+    op.Ho = Ho; op.Wo = Wo;
+    op.wid = c.pack_conv({{p + "conv.weight", p + "bn.", ""}}, cin_real, cin, k);
+    op.flops = 2.0 * x.B * Ho * Wo * (double)cout * k * k * cin_real;
+    c.push(op);
+    return y;
+}
+
+// BottleneckBlock (blocks.py:69-90): x + cv2(cv1(x)) iff shortcut and cin == cout
+static TV bottleneck(Ctx& c, const std::string& p, const TV& x, int cin, int cout, bool shortcut, float expansion,
+                     const TV* out_into = nullptr)
+{
+    const int hidden = (int)(cout * expansion);
+    TV u = conv_block(c, p + "cv1.", x, cin, hidden, 1, 1, true);
+    ConvOpt o;
+    o.out_into = out_into;
+    if (shortcut && cin == cout) o.res = &x;
+    return conv_block(c, p + "cv2.", u, hidden, cout, 3, 1, true, o);
+}
+
+// CSPBlock (blocks.py:93-123): cv3(cat(bottlenecks(cv1(x)), cv2(x)))
+static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int n, bool shortcut, float expansion,
+              const TV* out_into = nullptr)
+{
+    const int h = (int)(cout * expansion);
+    c.need(p + "cv1.conv.weight", {h, cin, 1, 1});
+    need_bn(c, p + "cv1.bn.", h);
+    c.need(p + "cv2.conv.weight", {h, cin, 1, 1});
+    need_bn(c, p + "cv2.bn.", h);
+    c.check_channels(cin, (p + "in_channels").c_str());
+    c.check_channels(h, (p + "hidden_channels").c_str());
+    if (x.C != cin) throw Error(SKY_ERR_SHAPE, p + ": input channel mismatch");
+    TV cat = c.new_tensor(x.B, x.H, x.W, 2 * h);
+    {   // cv1 | cv2 as one GEMM with N = 2h, written straight into the concat buffer
+        Op op;
+        op.kind = OP_CONV;
+        op.in = x; op.out = cat;
+        op.cin = cin; op.cout = 2 * h; op.ks = 1; op.stride = 1; op.act = ACT_SILU;
+        op.Ho = x.H; op.Wo = x.W;
+        op.wid = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}, {p + "cv2.conv.weight", p + "cv2.bn.", ""}}, cin, cin, 1);
+        op.flops = 2.0 * x.B * x.H * x.W * (double)(2 * h) * cin;
+        c.push(op);
+    }
+    TV y1 = Ctx::slice(cat, 0, h);
+    for (int j = 0; j < n; ++j)   // BottleneckBlock(hidden, hidden, shortcut, 1.0), blocks.py:114-117; in place on y1
+        bottleneck(c, p + "bottlenecks." + std::to_string(j) + ".", y1, h, h, shortcut, 1.0f, &y1);
+    ConvOpt o;
+    o.out_into = out_into;
+    return conv_block(c, p + "cv3.", cat, 2 * h, cout, 1, 1, true, o);
+}
+
+// SPPBlock (blocks.py:126-149), kernel sizes (5, 9, 13) = 5, 5o5, 5o5o5
+static TV spp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, const TV* out_into = nullptr)
+{
+    const int h = cin / 2;
+    TV cat = c.new_tensor(x.B, x.H, x.W, 4 * h);
+    TV s0 = Ctx::slice(cat, 0, h);
+    ConvOpt o1;
+    o1.out_into = &s0;
+    conv_block(c, p + "cv1.", x, cin, h, 1, 1, true, o1);
+    for (int i = 0; i < 3; ++i) {
+        Op op;
+        op.kind = OP_MAXPOOL5;
+        op.in = Ctx::slice(cat, i * h, h);
+        op.out = Ctx::slice(cat, (i + 1) * h, h);
+        c.push(op);
+    }
+    ConvOpt o2;
+    o2.out_into = out_into;
+    return conv_block(c, p + "cv2.", cat, 4 * h, cout, 1, 1, true, o2);
+}
+
+// ChannelAttention / SpatialAttention / CombinedAttention (attention.py:11-130)
+static TV cbam(Ctx& c, const std::string& p, const TV& x, int C, bool channel, bool spatial, int reduction, const TV* out_into = nullptr)
+{
+    const std::string pc = (channel && spatial) ? p + "channel_attention." : p;
+    const std::string ps = (channel && spatial) ? p + "spatial_attention." : p;
+    const int R = std::max(C / reduction, 1);
+    c.check_channels(C, (p + "channels").c_str());
+    if (x.C != C) throw Error(SKY_ERR_SHAPE, p + ": input channel mismatch");
+    TV y = out_into ? *out_into : c.new_tensor(x.B, x.H, x.W, C);
+    const int HW = x.H * x.W;
+    int att_buf = -1, gate_buf = -1;
+    if (channel) {
+        c.need(pc + "shared_mlp.0.weight", {R, C});
+        c.need(pc + "shared_mlp.2.weight", {C, R});
+        if (C > 2048 || R > 128) throw Error(SKY_ERR_INVALID, p + ": channel attention supports C <= 2048, C/r <= 128");
+        const int nchunk = std::max(1, std::min(64, HW / 256));
+        const int part = c.emit ? c.new_buf((size_t)x.B * nchunk * 2 * C * 4) : -1;
+        att_buf = c.emit ? c.new_buf((size_t)x.B * C * 4) : -1;
+        Op r;
+        r.kind = OP_CA_REDUCE; r.in = x; r.s0 = part; r.nchunk = nchunk;
+        c.push(r);
+        Op m;
+        m.kind = OP_CA_MLP; m.in = x; m.s0 = part; m.s1 = att_buf; m.nchunk = nchunk; m.R = R;
+        if (c.emit) { m.f0 = c.upload_f32(c.W(pc + "shared_mlp.0.weight").data); m.f1 = c.upload_f32(c.W(pc + "shared_mlp.2.weight").data); }
+        m.flops = 2.0 * x.B * 2 * 2 * (double)C * R;
+        c.push(m);
+    }
+    if (spatial) {
+        c.need(ps + "conv.weight", {1, 2, 7, 7});
+        const int stats = c.emit ? c.new_buf((size_t)x.B * HW * 2 * 4) : -1;
+        gate_buf = c.emit ? c.new_buf((size_t)x.B * HW * 4) : -1;
+        Op s;
+        s.kind = OP_SA_STATS; s.in = x; s.s0 = att_buf; s.s1 = stats;
+        c.push(s);
+        Op g;
+        g.kind = OP_SA_GATE; g.in = x; g.s0 = stats; g.s1 = gate_buf;
+        if (c.emit) g.f0 = c.upload_f32(c.W(ps + "conv.weight").data);
+        g.flops = 2.0 * x.B * HW * 98.0;
+        c.push(g);
+    }
+    Op a;
+    a.kind = OP_SCALE; a.in = x; a.out = y; a.s0 = att_buf; a.s1 = gate_buf;
+    c.push(a);
+    return y;
+}
+
+static int scaled_channels(int x, float wm) { return std::max((int)std::lround(std::nearbyint((double)x * wm)), 1); }
+// Python's round() is banker's rounding; nearbyint under the default FE_TONEAREST mode matches it.
+static int scaled_depth(int x, float dm) { return std::max((int)std::nearbyint((double)x * dm), 1); }
+
+struct BackboneOut {
+    TV p3, p4, p5;
+    int c3, c4, c5;
+};
+
+// import the caller's image tensor with FocusBlock's space-to-depth folded in (blocks.py:170-182)
+static TV import_focus(Ctx& c, int ext, int B, int C, int H, int W)
+{
+    if ((H & 1) || (W & 1)) throw Error(SKY_ERR_SHAPE, "FocusBlock needs even H and W");
+    const int epc = c.e.epc();
+    const int Cs = (4 * C + epc - 1) / epc * epc;
+    TV t = c.new_tensor(B, H / 2, W / 2, Cs);
+    Op op;
+    op.kind = OP_IMPORT;
+    op.in.ext = ext; op.out = t; op.s2d = 1; op.src_c = C; op.src_h = H; op.src_w = W;
+    c.push(op);
+    return t;
+}
+
+static TV import_plain(Ctx& c, int ext, int B, int C, int H, int W, const TV* into = nullptr)
+{
+    TV t = into ? *into : c.new_tensor(B, H, W, C);
+    Op op;
+    op.kind = OP_IMPORT;
+    op.in.ext = ext; op.out = t; op.s2d = 0; op.src_c = C; op.src_h = H; op.src_w = W;
+    c.push(op);
+    return t;
+}
+
+static void export_nchw(Ctx& c, const TV& t, int ext_out)
+{
+    Op op;
+    op.kind = OP_EXPORT;
+    op.in = t; op.out.ext = 16 + ext_out;
+    c.push(op);
+    if (c.emit) {
+        IoInfo io;
+        io.ndim = 4;
+        io.shape[0] = t.B; io.shape[1] = t.C; io.shape[2] = t.H; io.shape[3] = t.W;
+        if ((int)c.e.out_info.size() <= ext_out) c.e.out_info.resize(ext_out + 1);
+        c.e.out_info[ext_out] = io;
+    }
+}
+
+// FocusBlock as a standalone module / backbone stem
+static TV focus(Ctx& c, const std::string& p, int ext, int B, int C, int H, int W, int cout, int k)
+{
+    TV s = import_focus(c, ext, B, C, H, W);
+    ConvOpt o;
+    o.cin_real = 4 * C;
+    return conv_block(c, p + "conv.", s, s.C, cout, k, 1, true, o);
+}
+
+// Backbone.forward (backbone.py:82-99).  p3/p4/p5 may be directed into concat slots of the neck.
+static BackboneOut backbone(Ctx& c, const std::string& p, int ext, int B, int C, int H, int W, int base, float dm, float wm,
+                            const TV* p3_into, const TV* p4_into, const TV* p5_into)
+{
+    const int c1 = scaled_channels(base, wm), c2 = scaled_channels(base * 2, wm), c3 = scaled_channels(base * 4, wm);
+    const int c4 = scaled_channels(base * 8, wm), c5 = scaled_channels(base * 16, wm);
+    TV s = focus(c, p + "stage1.0.", ext, B, C, H, W, c1, 3);                                   // backbone.py:48
+    s = conv_block(c, p + "stage1.1.", s, c1, c2, 3, 2, true);                                  // :50
+    s = csp(c, p + "stage1.2.", s, c2, c2, scaled_depth(3, dm), true, 0.5f);                    // :52
+    s = conv_block(c, p + "stage2.0.", s, c2, c3, 3, 2, true);                                  // :58
+    TV p3 = csp(c, p + "stage2.1.", s, c3, c3, scaled_depth(9, dm), true, 0.5f, p3_into);       // :60
+    s = conv_block(c, p + "stage3.0.", p3, c3, c4, 3, 2, true);                                 // :66
+    s = csp(c, p + "stage3.1.", s, c4, c4, scaled_depth(9, dm), true, 0.5f);                    // :68
+    TV p4 = cbam(c, p + "stage3.2.", s, c4, true, true, 16, p4_into);                           // :70
+    s = conv_block(c, p + "stage4.0.", p4, c4, c5, 3, 2, true);                                 // :76
+    s = csp(c, p + "stage4.1.", s, c5, c5, scaled_depth(3, dm), true, 0.5f);                    // :78
+    TV p5 = spp(c, p + "stage4.2.", s, c5, c5, p5_into);                                        // :79
+    return {p3, p4, p5, c3, c4, c5};
+}
+
+struct NeckSlots {
+    TV cat_p4m, cat_p3m, cat_p4c, cat_p5c;   // concat buffers
+    TV p3, p4, p5;                           // where the backbone features must be written
+};
+
+static NeckSlots neck_alloc(Ctx& c, int B, int H3, int W3, int H4, int W4, int H5, int W5, int c3, int c4, int c5)
+{
+    NeckSlots n;
+    n.cat_p4m = c.new_tensor(B, H4, W4, 2 * c4);     // cat([up(lateral5(p5)), p4])   detector.py:215
+    n.cat_p3m = c.new_tensor(B, H3, W3, 2 * c3);     // cat([up(lateral4(p4)), p3])   detector.py:219
+    n.cat_p4c = c.new_tensor(B, H4, W4, c3 + c4);    // cat([down3(p3'), p4'])        detector.py:224
+    n.cat_p5c = c.new_tensor(B, H5, W5, c4 + c5);    // cat([down4(p4''), p5])        detector.py:228
+    n.p3 = Ctx::slice(n.cat_p3m, c3, c3);
+    n.p4 = Ctx::slice(n.cat_p4m, c4, c4);
+    n.p5 = Ctx::slice(n.cat_p5c, c4, c5);
+    return n;
+}
+
+// FeatureNeck.forward (detector.py:197-231); quirks kept: lateral_conv4 reads RAW p4, p5_cat takes RAW p5.
+static void neck(Ctx& c, const std::string& p, const NeckSlots& n, int c3, int c4, int c5, TV out[3])
+{
+    const TV &p3 = n.p3, &p4 = n.p4, &p5 = n.p5;
+    auto lateral = [&](const std::string& name, const TV& x, int cin, int cout, const TV& slot, int Ht, int Wt) {
+        if (Ht == 2 * x.H && Wt == 2 * x.W) {   // exact 2x: upsample in the epilogue
+            ConvOpt o;
+            o.out_into = &slot; o.up2 = true;
+            conv_block(c, p + name, x, cin, cout, 1, 1, true, o);
+        } else {                                // F.interpolate(size=...) for odd geometries
+            TV t = conv_block(c, p + name, x, cin, cout, 1, 1, true);
+            Op u;
+            u.kind = OP_UPSAMPLE; u.in = t; u.out = slot;
+            c.push(u);
+        }
+    };
+    lateral("lateral_conv5.", p5, c5, c4, Ctx::slice(n.cat_p4m, 0, c4), p4.H, p4.W);   // :210,214
+    lateral("lateral_conv4.", p4, c4, c3, Ctx::slice(n.cat_p3m, 0, c3), p3.H, p3.W);   // :211,218
+    TV p4p_slot = Ctx::slice(n.cat_p4c, c3, c4);
+    csp(c, p + "fpn_conv4.", n.cat_p4m, 2 * c4, c4, 3, true, 0.5f, &p4p_slot);          // :216
+    out[0] = csp(c, p + "fpn_conv3.", n.cat_p3m, 2 * c3, c3, 3, true, 0.5f);            // :220
+    ConvOpt d3;
+    TV d3_slot = Ctx::slice(n.cat_p4c, 0, c3);
+    d3.out_into = &d3_slot;
+    conv_block(c, p + "downsample3.", out[0], c3, c3, 3, 2, true, d3);                  // :223
+    out[1] = csp(c, p + "pan_conv4.", n.cat_p4c, c3 + c4, c4, 3, true, 0.5f);           // :225
+    ConvOpt d4;
+    TV d4_slot = Ctx::slice(n.cat_p5c, 0, c4);
+    d4.out_into = &d4_slot;
+    conv_block(c, p + "downsample4.", out[1], c4, c4, 3, 2, true, d4);                  // :227
+    out[2] = csp(c, p + "pan_conv5.", n.cat_p5c, c4 + c5, c5, 3, true, 0.5f);           // :229
+}
+
+// DetectionHead.forward + process_detections (detector.py:61-145) -> outputs [det, raw_0, ...]
+static void head(Ctx& c, const std::string& p, const TV* feats, int nl, int nc, int na, const float* anchors, int in_h, int in_w,
+                 int first_out)
+{
+    const int no = nc + 5;
+    long rows = 0;
+    for (int i = 0; i < nl; ++i) rows += (long)na * feats[i].H * feats[i].W;
+    long off = 0;
+    for (int i = 0; i < nl; ++i) {
+        const TV& f = feats[i];
+        const std::string l = p + "detection_layers." + std::to_string(i) + ".";
+        c.need(l + "weight", {na * no, f.C, 1, 1});
+        c.need(l + "bias", {na * no});
+        c.check_channels(f.C, (l + "in_channels").c_str());
+        if (na > 8) throw Error(SKY_ERR_INVALID, "at most 8 anchors per level");
+        Op op;
+        op.kind = OP_CONV;
+        op.in = f;
+        op.cin = f.C; op.cout = na * no; op.ks = 1; op.stride = 1; op.act = ACT_NONE;
+        op.Ho = f.H; op.Wo = f.W;
+        op.head = 1; op.level = i;
+        op.raw_ext = 16 + first_out + 1 + i;
+        op.det_ext = 16 + first_out;
+        op.det_rows = rows; op.det_off = off;
+        op.stride_px = (float)std::max((double)in_h / f.H, (double)in_w / f.W);          // detector.py:107-109
+        op.wid = c.pack_conv({{l + "weight", "", l + "bias"}}, f.C, f.C, 1);
+        op.flops = 2.0 * f.B * f.H * f.W * (double)(na * no) * f.C;
+        c.push(op);
+        off += (long)na * f.H * f.W;
+        if (c.emit) {
+            IoInfo io;
+            io.ndim = 5;
+            io.shape[0] = f.B; io.shape[1] = na; io.shape[2] = f.H; io.shape[3] = f.W; io.shape[4] = no;
+            if ((int)c.e.out_info.size() <= first_out + 1 + i) c.e.out_info.resize(first_out + 2 + i);
+            c.e.out_info[first_out + 1 + i] = io;
+        }
+    }
+    if (c.emit) {
+        IoInfo io;
+        io.ndim = 3;
+        io.shape[0] = feats[0].B; io.shape[1] = rows; io.shape[2] = no;
+        if ((int)c.e.out_info.size() <= first_out) c.e.out_info.resize(first_out + 1);
+        c.e.out_info[first_out] = io;
+    }
+    (void)anchors;
+}
+
+static const float kDefaultAnchors[18] = {10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326};   // detector.py:39-43
+
+// ------------------------------------------------------------------------------------------------ module dispatch
+struct Geometry {
+    int n = 0;
+    int64_t shape[SKY_MAX_IO][5];
+    int ndim[SKY_MAX_IO];
+};
+
+static void expect_inputs(const Geometry& g, int n, const char* mod)
+{
+    if (g.n != n) throw Error(SKY_ERR_SHAPE, std::string(mod) + ": expected " + std::to_string(n) + " input(s), got " + std::to_string(g.n));
+    for (int i = 0; i < n; ++i)
+        if (g.ndim[i] != 4) throw Error(SKY_ERR_SHAPE, std::string(mod) + ": inputs must be 4-D [B,C,H,W]");
+}
+
+static void build(Ctx& c, const Geometry& g)
+{
+    Engine& e = c.e;
+    const sky_config& cf = e.cfg;
+    auto dim = [&](int i, int d) { return (int)g.shape[i][d]; };
+    switch (cf.module) {
+        case SKY_MOD_CONV_BLOCK: {
+            expect_inputs(g, 1, "ConvolutionBlock");
+            TV x = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            export_nchw(c, conv_block(c, "", x, cf.c_in, cf.c_out, cf.kernel_size, cf.stride, cf.activation != 0), 0);
+            break;
+        }
+        case SKY_MOD_BOTTLENECK: {
+            expect_inputs(g, 1, "BottleneckBlock");
+            TV x = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            export_nchw(c, bottleneck(c, "", x, cf.c_in, cf.c_out, cf.shortcut != 0, cf.expansion), 0);
+            break;
+        }
+        case SKY_MOD_CSP: {
+            expect_inputs(g, 1, "CSPBlock");
+            TV x = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            export_nchw(c, csp(c, "", x, cf.c_in, cf.c_out, cf.num_blocks, cf.shortcut != 0, cf.expansion), 0);
+            break;
+        }
+        case SKY_MOD_SPP: {
+            expect_inputs(g, 1, "SPPBlock");
+            TV x = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            export_nchw(c, spp(c, "", x, cf.c_in, cf.c_out), 0);
+            break;
+        }
+        case SKY_MOD_FOCUS: {
+            expect_inputs(g, 1, "FocusBlock");
+            if (dim(0, 1) != cf.c_in) throw Error(SKY_ERR_SHAPE, "FocusBlock: input channel mismatch");
+            export_nchw(c, focus(c, "", 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3), cf.c_out, cf.kernel_size), 0);
+            break;
+        }
+        case SKY_MOD_CHANNEL_ATTENTION:
+        case SKY_MOD_SPATIAL_ATTENTION:
+        case SKY_MOD_COMBINED_ATTENTION: {
+            expect_inputs(g, 1, "attention");
+            TV x = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            const bool ch = cf.module != SKY_MOD_SPATIAL_ATTENTION, sp = cf.module != SKY_MOD_CHANNEL_ATTENTION;
+            export_nchw(c, cbam(c, "", x, dim(0, 1), ch, sp, cf.reduction_ratio > 0 ? cf.reduction_ratio : 16), 0);
+            break;
+        }
+        case SKY_MOD_BACKBONE: {
+            expect_inputs(g, 1, "Backbone");
+            BackboneOut b = backbone(c, "", 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3), cf.base_channels, cf.depth_multiple,
+                                     cf.width_multiple, nullptr, nullptr, nullptr);
+            export_nchw(c, b.p3, 0);
+            export_nchw(c, b.p4, 1);
+            export_nchw(c, b.p5, 2);
+            break;
+        }
+        case SKY_MOD_NECK: {
+            expect_inputs(g, 3, "FeatureNeck");
+            const int c3 = cf.level_channels[0], c4 = cf.level_channels[1], c5 = cf.level_channels[2];
+            NeckSlots n = neck_alloc(c, dim(0, 0), dim(0, 2), dim(0, 3), dim(1, 2), dim(1, 3), dim(2, 2), dim(2, 3), c3, c4, c5);
+            import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3), &n.p3);
+            import_plain(c, 1, dim(1, 0), dim(1, 1), dim(1, 2), dim(1, 3), &n.p4);
+            import_plain(c, 2, dim(2, 0), dim(2, 1), dim(2, 2), dim(2, 3), &n.p5);
+            TV out[3];
+            neck(c, "", n, c3, c4, c5, out);
+            for (int i = 0; i < 3; ++i) export_nchw(c, out[i], i);
+            break;
+        }
+        case SKY_MOD_HEAD: {
+            const int nl = cf.num_levels;
+            expect_inputs(g, nl, "DetectionHead");
+            TV f[SKY_MAX_LEVELS];
+            for (int i = 0; i < nl; ++i) f[i] = import_plain(c, i, dim(i, 0), dim(i, 1), dim(i, 2), dim(i, 3));
+            head(c, "", f, nl, cf.nc, cf.num_anchors, cf.anchors, cf.input_h, cf.input_w, 0);
+            break;
+        }
+        case SKY_MOD_DETECTOR: {
+            expect_inputs(g, 1, "SkyEyeDetector");
+            const int B = dim(0, 0), C = dim(0, 1), H = dim(0, 2), W = dim(0, 3);
+            if (H % 32 || W % 32) throw Error(SKY_ERR_SHAPE, "SkyEyeDetector: H and W must be multiples of the maximum stride 32 (check_img_size, general.py:248-268)");
+            const float wm = cf.width_multiple;
+            const int c3 = scaled_channels(cf.base_channels * 4, wm), c4 = scaled_channels(cf.base_channels * 8, wm),
+                      c5 = scaled_channels(cf.base_channels * 16, wm);
+            NeckSlots n = neck_alloc(c, B, H / 8, W / 8, H / 16, W / 16, H / 32, W / 32, c3, c4, c5);
+            backbone(c, "backbone.backbone.", 0, B, C, H, W, cf.base_channels, cf.depth_multiple, wm, &n.p3, &n.p4, &n.p5);
+            TV out[3];
+            neck(c, "neck.", n, c3, c4, c5, out);                                        // D1: neck width scale = 1
+            head(c, "detection_head.", out, 3, cf.nc, cf.num_anchors, cf.anchors, H, W, 0);
+            break;
+        }
+        case SKY_MOD_DECODE: {
+            // process_detections(outputs, input_shape): inputs are the raw levels [B, na, gh, gw, no]
+            const int nl = cf.num_levels, no = cf.nc + 5;
+            if (g.n != nl) throw Error(SKY_ERR_SHAPE, "process_detections: expected one raw tensor per level");
+            long rows = 0;
+            for (int i = 0; i < nl; ++i) {
+                if (g.ndim[i] != 5 || dim(i, 1) != cf.num_anchors || dim(i, 4) != no) throw Error(SKY_ERR_SHAPE, "process_detections: raw level must be [B, na, gh, gw, nc+5]");
+                rows += (long)cf.num_anchors * dim(i, 2) * dim(i, 3);
+            }
+            long off = 0;
+            for (int i = 0; i < nl; ++i) {
+                Op op;
+                op.kind = OP_DECODE;
+                op.in.ext = i; op.in.B = dim(i, 0);
+                op.level = i; op.Ho = dim(i, 2); op.Wo = dim(i, 3);
+                op.det_ext = 16; op.det_rows = rows; op.det_off = off;
+                op.stride_px = (float)std::max((double)cf.input_h / dim(i, 2), (double)cf.input_w / dim(i, 3));
+                c.push(op);
+                off += (long)cf.num_anchors * dim(i, 2) * dim(i, 3);
+            }
+            if (c.emit) {
+                IoInfo io;
+                io.ndim = 3;
+                io.shape[0] = dim(0, 0); io.shape[1] = rows; io.shape[2] = no;
+                c.e.out_info.assign(1, io);
+            }
+            break;
+        }
+        case SKY_MOD_UTILITY:
+            break;
+        default:
+            throw Error(SKY_ERR_INVALID, "module kind " + std::to_string(cf.module) + " is not implemented in this build");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ arena
+static void place_buffers(Engine& e)
+{
+    // greedy first-fit by first use; buffers whose lifetimes overlap never share bytes
+    std::vector<int> order;
+    for (int i = 0; i < (int)e.bufs.size(); ++i)
+        if (e.bufs[i].last >= 0) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        return e.bufs[a].first != e.bufs[b].first ? e.bufs[a].first < e.bufs[b].first : e.bufs[a].bytes > e.bufs[b].bytes;
+    });
+    std::vector<int> placed;
+    size_t top = 0;
+    for (int i : order) {
+        Buffer& b = e.bufs[i];
+        std::vector<std::pair<size_t, size_t>> busy;
+        for (int j : placed) {
+            const Buffer& o = e.bufs[j];
+            if (o.last < b.first || o.first > b.last) continue;
+            busy.push_back({o.offset, o.offset + o.bytes});
+        }
+        std::sort(busy.begin(), busy.end());
+        size_t pos = 0;
+        for (auto& iv : busy) {
+            if (pos + b.bytes <= iv.first) break;
+            pos = std::max(pos, iv.second);
+        }
+        b.offset = pos;
+        top = std::max(top, pos + b.bytes);
+        placed.push_back(i);
+    }
+    e.arena_bytes = std::max<size_t>(top, 256);
+}
+
+static void* tv_ptr(const Engine& e, const TV& t, const sky_buffer* ins, int n_in, const sky_buffer* outs, int n_out)
+{
+    if (t.ext >= 16) {
+        const int j = t.ext - 16;
+        if (j >= n_out) throw Error(SKY_ERR_INVALID, "output buffer " + std::to_string(j) + " not provided");
+        return outs[j].data;
+    }
+    if (t.ext >= 0) {
+        if (t.ext >= n_in) throw Error(SKY_ERR_INVALID, "input buffer " + std::to_string(t.ext) + " not provided");
+        return ins[t.ext].data;
+    }
+    if (t.buf < 0) return nullptr;
+    return e.arena + e.bufs[t.buf].offset + (size_t)t.off * e.esize();
+}
+
+static void* buf_ptr(const Engine& e, int buf) { return buf < 0 ? nullptr : (void*)(e.arena + e.bufs[buf].offset); }
+
+static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* outs, int n_out, hipStream_t s,
+                hipEvent_t* marks = nullptr)
+{
+    const sky_config& cf = e.cfg;
+    int op_index = 0;
+    if (marks) SKY_HIP(hipEventRecord(marks[0], s));
+    for (const Op& op : e.ops) {
+        switch (op.kind) {
+            case OP_IMPORT: {
+                const sky_buffer& src = ins[op.in.ext];
+                SKY_HIP(launch_import(e.dtype, src.data, src.dtype == SKY_IO_U8, src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                      op.out.B, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld, op.s2d, src.dtype == SKY_IO_U8, s));
+                break;
+            }
+            case OP_EXPORT:
+                SKY_HIP(launch_export(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (float*)tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                      op.in.B, op.in.C, op.in.H, op.in.W, s));
+                break;
+            case OP_CONV: {
+                ConvArgs a;
+                memset(&a, 0, sizeof(a));
+                const DevConv& d = e.convs[op.wid];
+                a.in = tv_ptr(e, op.in, ins, n_in, outs, n_out);
+                a.w = d.w; a.bias = d.bias; a.Kpad = d.Kpad;
+                a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.Cin = op.cin; a.ldi = op.in.ld;
+                a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.cout;
+                a.ks = op.ks; a.stride = op.stride; a.pad = op.ks / 2;
+                a.act = op.act; a.up2 = op.up2;
+                a.M = op.in.B * op.Ho * op.Wo;
+                if (op.head) {
+                    a.head = 1;
+                    TV r; r.ext = op.raw_ext;
+                    TV dt; dt.ext = op.det_ext;
+                    a.raw = (float*)tv_ptr(e, r, ins, n_in, outs, n_out);
+                    a.det = (float*)tv_ptr(e, dt, ins, n_in, outs, n_out);
+                    a.na = cf.num_anchors; a.no = cf.nc + 5;
+                    a.det_rows = op.det_rows; a.det_off = op.det_off; a.stride_px = op.stride_px;
+                    for (int k = 0; k < cf.num_anchors * 2; ++k)
+                        a.anchor_wh[k] = cf.anchors[op.level * cf.num_anchors * 2 + k] * op.stride_px;   // detector.py:119-121 (D13)
+                } else {
+                    a.out = tv_ptr(e, op.out, ins, n_in, outs, n_out);
+                    a.ldo = op.out.ld;
+                    if (op.res.valid()) { a.res = tv_ptr(e, op.res, ins, n_in, outs, n_out); a.ldr = op.res.ld; }
+                }
+                SKY_HIP(launch_conv(e.dtype, a, s));
+                break;
+            }
+            case OP_MAXPOOL5:
+                SKY_HIP(launch_maxpool5(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                        op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, s));
+                break;
+            case OP_UPSAMPLE:
+                SKY_HIP(launch_upsample(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                        op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s));
+                break;
+            case OP_CA_REDUCE:
+                SKY_HIP(launch_ca_reduce(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, op.in.B, op.in.H * op.in.W, op.in.C,
+                                         op.nchunk, (float*)buf_ptr(e, op.s0), s));
+                break;
+            case OP_CA_MLP:
+                SKY_HIP(launch_ca_mlp((const float*)buf_ptr(e, op.s0), op.in.B, op.in.H * op.in.W, op.in.C, op.nchunk, op.R, e.fweights[op.f0],
+                                      e.fweights[op.f1], (float*)buf_ptr(e, op.s1), s));
+                break;
+            case OP_SA_STATS:
+                SKY_HIP(launch_sa_stats(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (const float*)buf_ptr(e, op.s0), op.in.B,
+                                        op.in.H * op.in.W, op.in.C, (float*)buf_ptr(e, op.s1), s));
+                break;
+            case OP_SA_GATE:
+                SKY_HIP(launch_sa_gate((const float*)buf_ptr(e, op.s0), e.fweights[op.f0], op.in.B, op.in.H, op.in.W, (float*)buf_ptr(e, op.s1), s));
+                break;
+            case OP_DECODE: {
+                float awh[16];
+                for (int k = 0; k < cf.num_anchors * 2; ++k) awh[k] = cf.anchors[op.level * cf.num_anchors * 2 + k] * op.stride_px;
+                TV dt; dt.ext = op.det_ext;
+                SKY_HIP(launch_decode((const float*)ins[op.in.ext].data, (float*)tv_ptr(e, dt, ins, n_in, outs, n_out), op.in.B, cf.num_anchors,
+                                      op.Ho, op.Wo, cf.nc + 5, op.det_rows, op.det_off, op.stride_px, awh, s));
+                break;
+            }
+            case OP_SCALE:
+                SKY_HIP(launch_scale(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (const float*)buf_ptr(e, op.s0),
+                                     (const float*)buf_ptr(e, op.s1), tv_ptr(e, op.out, ins, n_in, outs, n_out), op.out.ld, op.in.B,
+                                     op.in.H * op.in.W, op.in.C, s));
+                break;
+        }
+        ++op_index;
+        if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
+    }
+}
+
+static void collect_spec(Engine& e)
+{
+    e.spec.clear();
+    Ctx c(e, false);
+    Geometry g;
+    const sky_config& cf = e.cfg;
+    auto set = [&](int i, int b, int ch, int h, int w) {
+        g.ndim[i] = 4;
+        g.shape[i][0] = b; g.shape[i][1] = ch; g.shape[i][2] = h; g.shape[i][3] = w; g.shape[i][4] = 0;
+    };
+    switch (cf.module) {
+        case SKY_MOD_DETECTOR: case SKY_MOD_ENHANCED_DETECTOR: case SKY_MOD_BACKBONE:
+            g.n = 1; set(0, 1, cf.in_channels, 64, 64); break;
+        case SKY_MOD_FOCUS:
+            g.n = 1; set(0, 1, cf.c_in, 64, 64); break;
+        case SKY_MOD_NECK:
+            g.n = 3;
+            for (int i = 0; i < 3; ++i) set(i, 1, cf.level_channels[i], 8 >> i, 8 >> i);
+            break;
+        case SKY_MOD_HEAD:
+            g.n = cf.num_levels;
+            for (int i = 0; i < cf.num_levels; ++i) set(i, 1, cf.level_channels[i], 8, 8);
+            break;
+        case SKY_MOD_CHANNEL_ATTENTION: case SKY_MOD_SPATIAL_ATTENTION: case SKY_MOD_COMBINED_ATTENTION:
+            g.n = 1; set(0, 1, cf.c_in > 0 ? cf.c_in : 16, 8, 8); break;   // SpatialAttention() has no channel argument
+        case SKY_MOD_DECODE: case SKY_MOD_UTILITY:
+            return;   // no parameters
+        default:
+            g.n = 1; set(0, 1, cf.c_in, 8, 8); break;
+    }
+    build(c, g);
+}
+
+static void plan(Engine& e, const Geometry& g)
+{
+    e.free_plan();
+    e.flops = e.act_bytes = e.weight_bytes = 0;
+    e.out_info.clear();
+    e.spec.clear();
+    Ctx c(e, true);
+    build(c, g);
+    place_buffers(e);
+    SKY_HIP(hipMalloc(&e.arena, e.arena_bytes));
+    for (const Op& op : e.ops) {
+        auto bytes = [&](const TV& t) { return t.valid() ? (double)t.B * t.H * t.W * t.C * e.esize() : 0.0; };
+        e.act_bytes += bytes(op.in) + bytes(op.out) + bytes(op.res);
+    }
+    e.planned = true;
+    e.weights_dirty = false;
+}
+
+}  // namespace sky
+
+using namespace sky;
+
+struct sky_handle {
+    Engine e;
+    Geometry geom;
+};
+
+template <typename F>
+static int guarded(sky_handle* h, F&& f)
+{
+    try {
+        f();
+        return SKY_OK;
+    } catch (const Error& er) {
+        if (h) h->e.err = er.what(); else g_create_error = er.what();
+        return er.code;
+    } catch (const std::exception& ex) {
+        if (h) h->e.err = ex.what(); else g_create_error = ex.what();
+        return SKY_ERR_INVALID;
+    }
+}
+
+extern "C" {
+
+int sky_abi_version(void) { return SKY_ABI_VERSION; }
+
+int sky_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* sky_last_error(const sky_handle* h) { return h ? h->e.err.c_str() : g_create_error.c_str(); }
+
+int sky_create(const sky_config* cfg, sky_handle** out)
+{
+    if (!cfg || !out) { g_create_error = "sky_create: null argument"; return SKY_ERR_INVALID; }
+    if (cfg->struct_size != sizeof(sky_config)) { g_create_error = "sky_create: sky_config size mismatch (ABI)"; return SKY_ERR_INVALID; }
+    sky_handle* h = nullptr;
+    int rc = guarded(nullptr, [&] {
+        h = new sky_handle();
+        h->e.cfg = *cfg;
+        h->e.dtype = cfg->dtype;
+        if (cfg->dtype != SKY_F32 && cfg->dtype != SKY_BF16) throw Error(SKY_ERR_INVALID, "unknown dtype");
+        sky_config& c = h->e.cfg;
+        if (c.base_channels <= 0) c.base_channels = 64;
+        if (c.depth_multiple <= 0) c.depth_multiple = 1.0f;
+        if (c.width_multiple <= 0) c.width_multiple = 1.0f;
+        if (c.in_channels <= 0) c.in_channels = 3;
+        if (c.num_levels <= 0) c.num_levels = 3;
+        if (c.num_anchors <= 0) {
+            c.num_anchors = 3;
+            memcpy(c.anchors, kDefaultAnchors, sizeof(kDefaultAnchors));
+        }
+        if (c.num_levels > SKY_MAX_LEVELS || c.num_anchors > SKY_MAX_ANCHORS) throw Error(SKY_ERR_INVALID, "too many levels / anchors");
+        if (c.expansion <= 0) c.expansion = 0.5f;
+        collect_spec(h->e);
+    });
+    if (rc != SKY_OK) { delete h; return rc; }
+    *out = h;
+    return SKY_OK;
+}
+
+void sky_destroy(sky_handle* h) { delete h; }
+
+int sky_num_params(const sky_handle* h) { return h ? (int)h->e.spec.size() : 0; }
+
+int sky_param_info(const sky_handle* h, int index, const char** name, int32_t* ndim, int64_t shape[4])
+{
+    if (!h || index < 0 || index >= (int)h->e.spec.size()) return SKY_ERR_INVALID;
+    const ParamSpec& p = h->e.spec[index];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int32_t)p.shape.size();
+    if (shape) for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 0;
+    return SKY_OK;
+}
+
+int sky_load_weights(sky_handle* h, const sky_tensor_desc* descs, int n)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        for (int i = 0; i < n; ++i) {
+            const sky_tensor_desc& d = descs[i];
+            if (!d.name || !d.data) throw Error(SKY_ERR_INVALID, "sky_load_weights: null name/data");
+            HostTensor t;
+            for (int k = 0; k < d.ndim; ++k) t.shape.push_back(d.shape[k]);
+            t.data.assign((const float*)d.data, (const float*)d.data + t.numel());
+            h->e.weights[d.name] = std::move(t);
+        }
+        h->e.weights_dirty = true;
+    });
+}
+
+int sky_plan(sky_handle* h, int n_inputs, const sky_buffer* in)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (n_inputs < 1 || n_inputs > SKY_MAX_IO) throw Error(SKY_ERR_INVALID, "sky_plan: bad input count");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(SKY_ERR_NO_DEVICE, "no HIP device visible: the HIP engine cannot run (there is no CPU fallback)");
+        SKY_HIP(hipSetDevice(h->e.cfg.device));
+        Geometry g;
+        g.n = n_inputs;
+        for (int i = 0; i < n_inputs; ++i) {
+            g.ndim[i] = in[i].ndim;
+            for (int k = 0; k < 5; ++k) g.shape[i][k] = k < in[i].ndim ? in[i].shape[k] : 0;
+            // boundary tensors are described logically as [B, C, H, W] whatever their memory layout
+        }
+        plan(h->e, g);
+        h->geom = g;
+    });
+}
+
+int sky_num_outputs(const sky_handle* h) { return h ? (int)h->e.out_info.size() : 0; }
+
+int sky_output_info(const sky_handle* h, int index, int32_t* ndim, int64_t shape[5])
+{
+    if (!h || index < 0 || index >= (int)h->e.out_info.size()) return SKY_ERR_INVALID;
+    const IoInfo& io = h->e.out_info[index];
+    if (ndim) *ndim = io.ndim;
+    if (shape) for (int i = 0; i < 5; ++i) shape[i] = io.shape[i];
+    return SKY_OK;
+}
+
+static void check_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs)
+{
+    if (!h->e.planned) throw Error(SKY_ERR_STATE, "sky_forward before sky_plan");
+    if (h->e.weights_dirty) throw Error(SKY_ERR_STATE, "weights changed after sky_plan: call sky_plan again");
+    if (n_inputs != h->geom.n) throw Error(SKY_ERR_SHAPE, "sky_forward: input count differs from the plan");
+    if (n_outputs != (int)h->e.out_info.size()) throw Error(SKY_ERR_SHAPE, "sky_forward: expected " + std::to_string(h->e.out_info.size()) + " outputs");
+    for (int i = 0; i < n_inputs; ++i) {
+        if (!inputs[i].data) throw Error(SKY_ERR_INVALID, "sky_forward: null input");
+        for (int k = 0; k < h->geom.ndim[i]; ++k)
+            if (inputs[i].shape[k] != h->geom.shape[i][k]) throw Error(SKY_ERR_SHAPE, "sky_forward: input shape differs from the plan");
+    }
+    for (int i = 0; i < n_outputs; ++i)
+        if (!outputs[i].data) throw Error(SKY_ERR_INVALID, "sky_forward: null output");
+}
+
+int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        check_forward(h, n_inputs, inputs, n_outputs, outputs);
+        run(h->e, inputs, n_inputs, outputs, n_outputs, (hipStream_t)stream);
+    });
+}
+
+int sky_time_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs, void* stream,
+                     int iters, float* ms_per_iter)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        check_forward(h, n_inputs, inputs, n_outputs, outputs);
+        hipStream_t s = (hipStream_t)stream;
+        hipEvent_t e0, e1;
+        SKY_HIP(hipEventCreate(&e0));
+        SKY_HIP(hipEventCreate(&e1));
+        SKY_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run(h->e, inputs, n_inputs, outputs, n_outputs, s);
+        SKY_HIP(hipEventRecord(e1, s));
+        SKY_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        SKY_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (ms_per_iter) *ms_per_iter = ms / (float)std::max(iters, 1);
+    });
+}
+
+int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs, void* stream,
+                        int iters, int max_ops, float* ms_per_op, double* flops_per_op, int32_t* tag_per_op, int32_t* n_ops)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        check_forward(h, n_inputs, inputs, n_outputs, outputs);
+        const int n = (int)h->e.ops.size();
+        if (n_ops) *n_ops = n;
+        if (n > max_ops) throw Error(SKY_ERR_INVALID, "sky_profile_forward: max_ops too small");
+        hipStream_t s = (hipStream_t)stream;
+        std::vector<hipEvent_t> ev(n + 1);
+        for (auto& e : ev) SKY_HIP(hipEventCreate(&e));
+        std::vector<double> acc(n, 0.0);
+        for (int it = 0; it < iters; ++it) {
+            run(h->e, inputs, n_inputs, outputs, n_outputs, s, ev.data());
+            SKY_HIP(hipEventSynchronize(ev[n]));
+            for (int i = 0; i < n; ++i) {
+                float ms = 0;
+                SKY_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+                acc[i] += ms;
+            }
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < n; ++i) {
+            const Op& op = h->e.ops[i];
+            if (ms_per_op) ms_per_op[i] = (float)(acc[i] / std::max(iters, 1));
+            if (flops_per_op) flops_per_op[i] = op.flops;
+            if (tag_per_op) tag_per_op[i] = (int)op.kind * 1000 + (op.kind == OP_CONV ? conv_pick_bn(op.cout) : 0);
+        }
+    });
+}
+
+int sky_plan_stats(const sky_handle* h, double* flops, double* activation_bytes, double* weight_bytes, int32_t* launches)
+{
+    if (!h || !h->e.planned) return SKY_ERR_STATE;
+    if (flops) *flops = h->e.flops;
+    if (activation_bytes) *activation_bytes = h->e.act_bytes;
+    if (weight_bytes) *weight_bytes = h->e.weight_bytes;
+    if (launches) *launches = (int32_t)h->e.ops.size();
+    return SKY_OK;
+}
+
+int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms_params* p, float* out, int32_t* counts, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!det || !p || !out || !counts) throw Error(SKY_ERR_INVALID, "sky_nms: null argument");
+        if (p->struct_size != sizeof(sky_nms_params)) throw Error(SKY_ERR_INVALID, "sky_nms: sky_nms_params size mismatch (ABI)");
+        if (B < 1 || N < 1 || nc < 1) throw Error(SKY_ERR_SHAPE, "sky_nms: bad geometry");
+        if (p->max_detections < 1 || p->max_detections > 4096) throw Error(SKY_ERR_INVALID, "sky_nms: max_detections must be in [1, 4096]");
+        if (p->n_classes > 64) throw Error(SKY_ERR_INVALID, "sky_nms: at most 64 class filters");
+        NmsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.det = det; a.B = B; a.N = N; a.nc = nc;
+        a.conf = p->conf_threshold; a.iou = p->iou_threshold; a.max_wh = p->max_wh;
+        a.agnostic = p->agnostic; a.max_det = p->max_detections; a.max_nms = p->max_nms; a.mode = p->mode;
+        a.multi_label = p->multi_label && nc > 1;       // metrics.py:396
+        a.n_classes = p->n_classes;
+        for (int i = 0; i < p->n_classes; ++i) a.classes[i] = p->classes[i];
+        a.out = out; a.counts = counts;
+        long cap = 0;
+        const size_t need = nms_workspace_bytes(B, N, nc, a.multi_label, &cap);
+        if (need > h->e.nms_ws_bytes) {
+            if (h->e.nms_ws) (void)hipFree(h->e.nms_ws);
+            h->e.nms_ws = nullptr;
+            SKY_HIP(hipMalloc(&h->e.nms_ws, need));
+            h->e.nms_ws_bytes = need;
+        }
+        a.cap = cap;
+        char* w = (char*)h->e.nms_ws;
+        const int nblk = (N + 255) / 256;
+        a.blk_counts = (int*)w; w += ((size_t)B * nblk * sizeof(int) + 255) / 256 * 256;
+        a.totals = (int*)w; w += ((size_t)B * sizeof(int) + 255) / 256 * 256;
+        a.keys = (unsigned long long*)w; w += (size_t)B * cap * sizeof(unsigned long long);
+        a.cand = (float*)w;
+        SKY_HIP(launch_nms(a, (hipStream_t)stream));
+    });
+}
+
+int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        SKY_HIP(hipMemcpyAsync(counts_host, counts_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        SKY_HIP(hipStreamSynchronize((hipStream_t)stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,452 @@
+// Layout glue, pooling, upsampling and the CBAM reductions for gfx950.  All of these are HBM-bound
+// byte movers: 16 bytes per lane, channel-contiguous NHWC, grid-stride loops capped near 8 blocks per CU.
+#include "sky_kernels.h"
+
+#include <hip/hip_bf16.h>
+#include <math.h>
+
+namespace sky {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+static inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 2048 * 4 ? 2048 * 4 : blocks)); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// 16-byte vector of T as floats
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const f32x4_t r = *reinterpret_cast<const f32x4_t*>(p);
+        v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct Vec<__bf16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const __bf16* p, float* v) {
+        const u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __uint_as_float(r[e] << 16);
+            v[2 * e + 1] = __uint_as_float(r[e] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(__bf16* p, const float* v) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+            o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+        }
+        *reinterpret_cast<u32x4_t*>(p) = o;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ import
+// dst[b, y, x, c] (NHWC, pitch ld, C padded with zeros up to Cpad).  With s2d the destination pixel (y, x)
+// gathers the 2x2 source block: channel p*C + c with p = 0 TL, 1 BL, 2 TR, 3 BR (blocks.py:176-181).
+template <typename T, typename S>
+__global__ void import_kernel(const S* __restrict__ src, int src_nhwc, T* __restrict__ dst, int B, int C, int H, int W,
+                              int Cpad, int ld, int s2d, int scale255)
+{
+    const int Ho = s2d ? H / 2 : H, Wo = s2d ? W / 2 : W;
+    const int Cs = s2d ? 4 * C : C;
+    const long total = (long)B * Ho * Wo * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long p = i / Cpad;
+        const int x = (int)(p % Wo);
+        const long t = p / Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float v = 0.0f;
+        if (c < Cs) {
+            int sc = c, sy = y, sx = x;
+            if (s2d) {
+                const int patch = c / C;
+                sc = c - patch * C;
+                sy = 2 * y + (patch & 1);
+                sx = 2 * x + (patch >> 1);
+            }
+            const long si = src_nhwc ? (((long)b * H + sy) * W + sx) * C + sc : (((long)b * C + sc) * H + sy) * W + sx;
+            v = (float)src[si];
+            if (scale255) v = v / 255.0f;
+        }
+        dst[p * ld + c] = from_f32<T>(v);
+    }
+}
+
+hipError_t launch_import(int dtype, const void* src, int src_u8, int src_nhwc, void* dst, int B, int C, int H, int W,
+                         int Cpad, int ld, int s2d, int scale255, hipStream_t s)
+{
+    const long total = (long)B * (s2d ? H / 2 : H) * (s2d ? W / 2 : W) * Cpad;
+    const int grid = cap_grid((total + 255) / 256);
+#define SKY_IMPORT(T, S) \
+    hipLaunchKernelGGL((import_kernel<T, S>), dim3(grid), dim3(256), 0, s, (const S*)src, src_nhwc, (T*)dst, B, C, H, W, Cpad, ld, s2d, scale255)
+    if (dtype == 0) { if (src_u8) SKY_IMPORT(float, unsigned char); else SKY_IMPORT(float, float); }
+    else            { if (src_u8) SKY_IMPORT(__bf16, unsigned char); else SKY_IMPORT(__bf16, float); }
+#undef SKY_IMPORT
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ export
+template <typename T>
+__global__ void export_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int B, int C, int H, int W)
+{
+    // tile transpose through LDS: 32 pixels x 32 channels
+    __shared__ float tile[32][33];
+    const long HW = (long)H * W;
+    const int ptiles = (int)((HW + 31) / 32), ctiles = (C + 31) / 32;
+    const long ntile = (long)B * ptiles * ctiles;
+    for (long tIdx = blockIdx.x; tIdx < ntile; tIdx += gridDim.x) {
+        const int ct = (int)(tIdx % ctiles);
+        const long r = tIdx / ctiles;
+        const int pt = (int)(r % ptiles);
+        const int b = (int)(r / ptiles);
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+        for (int k = ty; k < 32; k += 8) {
+            const long p = (long)pt * 32 + k;
+            const int c = ct * 32 + tx;
+            tile[k][tx] = (p < HW && c < C) ? to_f32<T>(src[((long)b * HW + p) * ld + c]) : 0.0f;
+        }
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8) {
+            const int c = ct * 32 + k;
+            const long p = (long)pt * 32 + tx;
+            if (p < HW && c < C) dst[((long)b * C + c) * HW + p] = tile[tx][k];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s)
+{
+    const long ntile = (long)B * (((long)H * W + 31) / 32) * ((C + 31) / 32);
+    const int grid = cap_grid(ntile);
+    if (dtype == 0) hipLaunchKernelGGL(export_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, ld, dst, B, C, H, W);
+    else hipLaunchKernelGGL(export_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, ld, dst, B, C, H, W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ max pool 5x5
+template <typename T>
+__global__ void maxpool5_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int B, int H, int W, int C)
+{
+    constexpr int N = Vec<T>::N;
+    const int cg = C / N;
+    const long total = (long)B * H * W * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long p = i / cg;
+        const int x = (int)(p % W);
+        const long t = p / W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        float m[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) m[e] = -INFINITY;
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                float v[N];
+                Vec<T>::load(src + (((long)b * H + yy) * W + xx) * lds_ + g * N, v);
+#pragma unroll
+                for (int e = 0; e < N; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        Vec<T>::store(dst + p * ldd + g * N, m);
+    }
+}
+
+hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, hipStream_t s)
+{
+    const int N = dtype == 0 ? 4 : 8;
+    const long total = (long)B * H * W * (C / N);
+    const int grid = cap_grid((total + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(maxpool5_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, lds_, (float*)dst, ldd, B, H, W, C);
+    else hipLaunchKernelGGL(maxpool5_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ nearest upsample
+template <typename T>
+__global__ void upsample_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int B, int H, int W, int C,
+                                int Ho, int Wo)
+{
+    constexpr int N = Vec<T>::N;
+    const int cg = C / N;
+    const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+    const long total = (long)B * Ho * Wo * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long p = i / cg;
+        const int x = (int)(p % Wo);
+        const long t = p / Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        int sy = (int)floorf((float)y * sh), sx = (int)floorf((float)x * sw);
+        sy = sy > H - 1 ? H - 1 : sy;
+        sx = sx > W - 1 ? W - 1 : sx;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + (((long)b * H + sy) * W + sx) * lds_ + g * N);
+        *reinterpret_cast<u32x4_t*>(dst + p * ldd + g * N) = v;
+    }
+}
+
+hipError_t launch_upsample(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int Ho, int Wo,
+                           hipStream_t s)
+{
+    const int N = dtype == 0 ? 4 : 8;
+    const long total = (long)B * Ho * Wo * (C / N);
+    const int grid = cap_grid((total + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, lds_, (float*)dst, ldd, B, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(upsample_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C, Ho, Wo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+struct AnchorPack { float wh[16]; };
+
+__global__ void decode_kernel(const float* __restrict__ raw, float* __restrict__ det, int B, int na, int gh, int gw, int no,
+                              long det_rows, long det_off, float stride_px, AnchorPack an)
+{
+#pragma clang fp contract(off)
+    const long total = (long)B * na * gh * gw * no;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % no);
+        const long cell = i / no;
+        const int x = (int)(cell % gw);
+        long t = cell / gw;
+        const int y = (int)(t % gh);
+        t /= gh;
+        const int a = (int)(t % na);
+        const int b = (int)(t / na);
+        const float s = 1.0f / (1.0f + expf(-raw[i]));
+        float d;
+        if (o == 0) d = (s * 2.0f - 0.5f + (float)x) * stride_px;
+        else if (o == 1) d = (s * 2.0f - 0.5f + (float)y) * stride_px;
+        else if (o == 2 || o == 3) { const float t2 = s * 2.0f; d = (t2 * t2) * an.wh[a * 2 + (o - 2)]; }
+        else d = s;
+        det[((long)b * det_rows + det_off + ((long)a * gh + y) * gw + x) * no + o] = d;
+    }
+}
+
+hipError_t launch_decode(const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
+                         float stride_px, const float* anchor_wh, hipStream_t s)
+{
+    AnchorPack an;
+    for (int i = 0; i < 16; ++i) an.wh[i] = i < na * 2 ? anchor_wh[i] : 0.0f;
+    const long total = (long)B * na * gh * gw * no;
+    hipLaunchKernelGGL(decode_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, raw, det, B, na, gh, gw, no, det_rows, det_off,
+                       stride_px, an);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ CBAM
+// ChannelAttention pooling (attention.py:50,54): per (b, c) sum and max over H*W, split into `nchunk` pixel
+// ranges so the result does not depend on atomics (deterministic): part[b][chunk][0][c] = sum, [1][c] = max.
+template <typename T>
+__global__ void ca_reduce_kernel(const T* __restrict__ x, int ld, int HW, int C, int nchunk, float* __restrict__ part)
+{
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const long per = ((long)HW + nchunk - 1) / nchunk;
+    const long p0 = chunk * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.0f, m = -INFINITY;
+        for (long p = p0; p < p1; ++p) {
+            const float v = to_f32<T>(x[((long)b * HW + p) * ld + c]);
+            s += v;
+            m = v > m ? v : m;
+        }
+        float* o = part + ((long)(b * nchunk + chunk) * 2) * C;
+        o[c] = s;
+        o[C + c] = m;
+    }
+}
+
+hipError_t launch_ca_reduce(int dtype, const void* x, int ld, int B, int HW, int C, int nchunk, float* part, hipStream_t s)
+{
+    if (dtype == 0) hipLaunchKernelGGL(ca_reduce_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, (const float*)x, ld, HW, C, nchunk, part);
+    else hipLaunchKernelGGL(ca_reduce_kernel<__bf16>, dim3(nchunk, B), dim3(256), 0, s, (const __bf16*)x, ld, HW, C, nchunk, part);
+    return hipGetLastError();
+}
+
+// shared MLP: Linear(C->R, no bias) -> ReLU -> Linear(R->C, no bias); att = sigmoid(mlp(avg) + mlp(max))
+// (attention.py:29-34, 49-58).  One block per image; C <= 2048, R <= 128.
+__global__ void ca_mlp_kernel(const float* __restrict__ part, int HW, int C, int nchunk, int R, const float* __restrict__ w0,
+                              const float* __restrict__ w2, float* __restrict__ att)
+{
+    extern __shared__ float sm[];
+    float* avg = sm;            // [C]
+    float* mx = sm + C;         // [C]
+    float* ha = sm + 2 * C;     // [R]
+    float* hm = ha + R;         // [R]
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.0f, m = -INFINITY;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* o = part + ((long)(b * nchunk + k) * 2) * C;
+            s += o[c];
+            m = o[C + c] > m ? o[C + c] : m;
+        }
+        avg[c] = s / (float)HW;
+        mx[c] = m;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float sa = 0.0f, sx = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float w = w0[(long)r * C + c];
+            sa += w * avg[c];
+            sx += w * mx[c];
+        }
+        ha[r] = sa > 0.0f ? sa : 0.0f;
+        hm[r] = sx > 0.0f ? sx : 0.0f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float oa = 0.0f, om = 0.0f;
+        for (int r = 0; r < R; ++r) {
+            const float w = w2[(long)c * R + r];
+            oa += w * ha[r];
+            om += w * hm[r];
+        }
+        const float z = oa + om;
+        att[(long)b * C + c] = 1.0f / (1.0f + expf(-z));
+    }
+}
+
+hipError_t launch_ca_mlp(const float* part, int B, int HW, int C, int nchunk, int R, const float* w0, const float* w2, float* att,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(ca_mlp_kernel, dim3(B), dim3(256), (2 * C + 2 * R) * sizeof(float), s, part, HW, C, nchunk, R, w0, w2, att);
+    return hipGetLastError();
+}
+
+// SpatialAttention statistics (attention.py:91-92): mean and max over channels of x (optionally pre-scaled by the
+// channel gate, which is CombinedAttention's x1 = x * att).  One wave per pixel, lanes stride the channels.
+template <typename T>
+__global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __restrict__ att, int B, int HW, int C,
+                                float* __restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwave = ((long)gridDim.x * blockDim.x) >> 6;
+    const long total = (long)B * HW;
+    for (long p = wave; p < total; p += nwave) {
+        const int b = (int)(p / HW);
+        float s = 0.0f, m = -INFINITY;
+        for (int c = lane; c < C; c += 64) {
+            float v = to_f32<T>(x[p * ld + c]);
+            if (att) v = v * att[(long)b * C + c];
+            s += v;
+            m = v > m ? v : m;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            const float mo = __shfl_xor(m, o);
+            m = mo > m ? mo : m;
+        }
+        if (lane == 0) {
+            stats[p * 2] = s / (float)C;
+            stats[p * 2 + 1] = m;
+        }
+    }
+}
+
+hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, int B, int HW, int C, float* stats, hipStream_t s)
+{
+    const long total = (long)B * HW;
+    const int grid = cap_grid((total + 3) / 4);
+    if (dtype == 0) hipLaunchKernelGGL(sa_stats_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, att, B, HW, C, stats);
+    else hipLaunchKernelGGL(sa_stats_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ld, att, B, HW, C, stats);
+    return hipGetLastError();
+}
+
+// gate[b, y, x] = sigmoid(conv7x7(stats)) with weights w[0][ch][ky][kx], ch 0 = mean, 1 = max (attention.py:79,95-96)
+__global__ void sa_gate_kernel(const float* __restrict__ stats, const float* __restrict__ w, int B, int H, int W,
+                               float* __restrict__ gate)
+{
+    __shared__ float ws[98];
+    if (threadIdx.x < 98) ws[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const long total = (long)B * H * W;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % W);
+        const long t = p / W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        float acc = 0.0f;
+        for (int ch = 0; ch < 2; ++ch)
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yy = y + ky - 3;
+                if ((unsigned)yy >= (unsigned)H) continue;
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int xx = x + kx - 3;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    acc += ws[(ch * 7 + ky) * 7 + kx] * stats[(((long)b * H + yy) * W + xx) * 2 + ch];
+                }
+            }
+        gate[p] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+hipError_t launch_sa_gate(const float* stats, const float* w, int B, int H, int W, float* gate, hipStream_t s)
+{
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(sa_gate_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, stats, w, B, H, W, gate);
+    return hipGetLastError();
+}
+
+// out[b, p, c] = (x[b, p, c] * att[b, c]) * gate[b, p]   (attention.py:60,98)
+template <typename T>
+__global__ void scale_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ att, const float* __restrict__ gate,
+                             T* __restrict__ out, int ldo, int B, int HW, int C)
+{
+    constexpr int N = Vec<T>::N;
+    const int cg = C / N;
+    const long total = (long)B * HW * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long p = i / cg;
+        const int b = (int)(p / HW);
+        float v[N];
+        Vec<T>::load(x + p * ldx + g * N, v);
+        if (att) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * att[(long)b * C + g * N + e];
+        }
+        if (gate) {
+            const float gt = gate[p];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * gt;
+        }
+        Vec<T>::store(out + p * ldo + g * N, v);
+    }
+}
+
+hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, const float* gate, void* out, int ldo, int B, int HW,
+                        int C, hipStream_t s)
+{
+    const int N = dtype == 0 ? 4 : 8;
+    const long total = (long)B * HW * (C / N);
+    const int grid = cap_grid((total + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(scale_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, att, gate, (float*)out, ldo, B, HW, C);
+    else hipLaunchKernelGGL(scale_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldx, att, gate, (__bf16*)out, ldo, B, HW, C);
+    return hipGetLastError();
+}
+
+}  // namespace sky

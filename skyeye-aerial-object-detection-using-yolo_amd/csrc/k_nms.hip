@@ -1,0 +1,331 @@
+// Per-image non-maximum suppression on gfx950.
+//
+// Replaces non_max_suppression (reference skyeye/utils/metrics.py:361-457) including the greedy suppression it
+// delegates to torchvision.ops.nms (call site metrics.py:442; semantics restated in oracle/sky_oracle_nms.c).
+//
+//   1. count    per 256-row block: how many candidate entries the rows produce   (metrics.py:389,402-422,425-426)
+//   2. scan     exclusive scan of the block counts per image (deterministic, ordered compaction - no atomics)
+//   3. emit     candidate records in (row, class) order + 64-bit sort keys
+//               key = ~monotone(score) << 32 | candidate index  => ascending key order is "score descending,
+//               lower index first", the tie rule fixed by this build
+//   4. sort     bitonic sort of the keys, per image, padded to a power of two; chunks of 4096 keys in LDS
+//   5. greedy   one wavefront per image walks the sorted candidates 64 at a time: each lane tests its box against
+//               the kept list (LDS), then the 64 lanes resolve among themselves in score order with ballots;
+//               stops at max_det kept or max_nms visited (metrics.py:434-435,443-444)
+//
+// This file is compiled with -ffp-contract=off: IoU and the class-offset arithmetic must round exactly like the
+// fp32 tensor ops of the reference so that the kept set is bit-identical to the oracle's.
+#include "sky_kernels.h"
+
+#include <math.h>
+
+namespace sky {
+
+static constexpr int ROWS = 256;        // rows per count/emit block
+static constexpr int CHUNK = 4096;      // keys per LDS sort block
+static constexpr int SORT_T = 512;      // threads per sort block
+
+__device__ __forceinline__ unsigned int score_key(float s)
+{
+    unsigned int u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending float order
+    return ~u;                                        // descending
+}
+
+__device__ __forceinline__ bool class_ok(const NmsArgs& a, float c5)
+{
+    if (a.n_classes <= 0) return true;
+    bool hit = false;
+    for (int c = 0; c < a.n_classes; ++c) hit |= (c5 == (float)a.classes[c]);
+    return hit;
+}
+
+// Enumerate the candidate entries of one prediction row in the reference's order; f(score, c5, c6).
+template <typename F>
+__device__ __forceinline__ void row_entries(const NmsArgs& a, const float* __restrict__ p, F&& f)
+{
+    const int nc = a.nc;
+    const float obj = p[4];
+    if (!(obj > a.conf)) return;                                   // metrics.py:389,402
+    if (a.mode == 0) {
+        if (nc > 1) {
+            if (a.multi_label) {                                   // metrics.py:412-413
+                for (int j = 0; j < nc; ++j) {
+                    const float c = p[5 + j];
+                    if (c > a.conf && class_ok(a, c)) f(obj, c, (float)j);
+                }
+            } else {                                               // metrics.py:416-417 (first maximal index)
+                int bj = 0;
+                float bc = p[5];
+                for (int j = 1; j < nc; ++j) {
+                    const float c = p[5 + j];
+                    if (c > bc) { bc = c; bj = j; }
+                }
+                if (bc > a.conf && class_ok(a, bc)) f(obj, bc, (float)bj);
+            }
+        } else {                                                   // metrics.py:420-422
+            if (class_ok(a, 0.0f)) f(obj, 0.0f, 0.0f);
+        }
+    } else {                                                       // corrected: conf = obj * cls, class id in col 5
+        if (a.multi_label && nc > 1) {
+            for (int j = 0; j < nc; ++j) {
+                const float c = p[5 + j] * obj;
+                if (c > a.conf && class_ok(a, (float)j)) f(c, (float)j, 0.0f);
+            }
+        } else {
+            int bj = 0;
+            float bc = p[5] * obj;
+            for (int j = 1; j < nc; ++j) {
+                const float c = p[5 + j] * obj;
+                if (c > bc) { bc = c; bj = j; }
+            }
+            if (bc > a.conf && class_ok(a, (float)bj)) f(bc, (float)bj, 0.0f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(ROWS) nms_count_kernel(const NmsArgs a, int nblk)
+{
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int i = blk * ROWS + threadIdx.x;
+    int cnt = 0;
+    if (i < a.N) row_entries(a, a.det + ((long)b * a.N + i) * (a.nc + 5), [&](float, float, float) { ++cnt; });
+    __shared__ int red[ROWS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < ROWS / 64; ++w) s += red[w];
+        a.blk_counts[(long)b * nblk + blk] = s;
+    }
+}
+
+// in-place exclusive scan of blk_counts[b][0..nblk); totals[b] = sum.  One block of 256 threads per image.
+__global__ void __launch_bounds__(256) nms_scan_kernel(const NmsArgs a, int nblk)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    int* c = a.blk_counts + (long)b * nblk;
+    const int per = (nblk + 255) / 256;
+    const int i0 = t * per, i1 = (i0 + per < nblk) ? i0 + per : nblk;
+    int s = 0;
+    for (int i = i0; i < i1; ++i) s += c[i];
+    __shared__ int part[256];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = run; run += v; }
+        a.totals[b] = run;
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int i = i0; i < i1; ++i) { const int v = c[i]; c[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(ROWS) nms_emit_kernel(const NmsArgs a, int nblk)
+{
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int i = blk * ROWS + threadIdx.x;
+    const float* p = a.det + ((long)b * a.N + i) * (a.nc + 5);
+    int cnt = 0;
+    if (i < a.N) row_entries(a, p, [&](float, float, float) { ++cnt; });
+    // exclusive scan of cnt over the block (row order)
+    __shared__ int sc[ROWS];
+    sc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < ROWS; o <<= 1) {
+        const int v = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    long k = (long)a.blk_counts[(long)b * nblk + blk] + (sc[threadIdx.x] - cnt);
+    if (i < a.N && cnt) {
+        row_entries(a, p, [&](float score, float c5, float c6) {
+            if (k < a.cap) {
+                a.keys[(long)b * a.cap + k] = ((unsigned long long)score_key(score) << 32) | (unsigned int)k;
+                float* r = a.cand + ((long)b * a.cap + k) * 4;
+                r[0] = score; r[1] = c5; r[2] = c6; r[3] = __int_as_float(i);
+            }
+            ++k;
+        });
+    }
+}
+
+__device__ __forceinline__ long padded_len(int total)
+{
+    long p = 1;
+    while (p < total) p <<= 1;
+    return p;
+}
+
+// keys[total .. padded) = ~0 so they sort last
+__global__ void __launch_bounds__(256) nms_pad_kernel(const NmsArgs a)
+{
+    const int b = blockIdx.y;
+    const int total = a.totals[b];
+    const long P = padded_len(total);
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= total && k < P && k < a.cap) a.keys[(long)b * a.cap + k] = ~0ull;
+}
+
+// bitonic sort inside LDS.  full = 1: sort the chunk from k = 2; full = 0: only the merge tail (j = CHUNK/2 .. 1)
+// of global stage `kstage`.
+__global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a, int full, long kstage)
+{
+    const int b = blockIdx.y;
+    const long P = padded_len(a.totals[b]);
+    const long base = (long)blockIdx.x * CHUNK;
+    if (base >= P || (!full && kstage > P)) return;
+    const long len = P < CHUNK ? P : CHUNK;
+    __shared__ unsigned long long sk[CHUNK];
+    unsigned long long* g = a.keys + (long)b * a.cap + base;
+    for (int i = threadIdx.x; i < len; i += SORT_T) sk[i] = g[i];
+    __syncthreads();
+    const long k0 = full ? 2 : kstage;
+    const long k1 = full ? len : kstage;
+    for (long k = k0; k <= k1; k <<= 1) {
+        long jstart = k >> 1;
+        if (jstart > len / 2) jstart = len / 2;
+        for (long j = jstart; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < len / 2; t += SORT_T) {
+                const int lo = (int)(((t / j) * 2 * j) + (t % j));
+                const int hi = lo + (int)j;
+                const bool asc = (((base + lo) & k) == 0);
+                const unsigned long long x = sk[lo], y = sk[hi];
+                if ((x > y) == asc) { sk[lo] = y; sk[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < len; i += SORT_T) g[i] = sk[i];
+}
+
+// one global compare-exchange step (j >= CHUNK) of stage k
+__global__ void __launch_bounds__(256) nms_sort_global_kernel(const NmsArgs a, long k, long j)
+{
+    const int b = blockIdx.y;
+    const long P = padded_len(a.totals[b]);
+    if (k > P) return;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= P / 2) return;
+    const long lo = (t / j) * 2 * j + (t % j);
+    const long hi = lo + j;
+    unsigned long long* g = a.keys + (long)b * a.cap;
+    const bool asc = ((lo & k) == 0);
+    const unsigned long long x = g[lo], y = g[hi];
+    if ((x > y) == asc) { g[lo] = y; g[hi] = x; }
+}
+
+__device__ __forceinline__ bool iou_gt(float kx1, float ky1, float kx2, float ky2, float karea, float x1, float y1, float x2,
+                                       float y2, float area, float thr)
+{
+    float w = fminf(kx2, x2) - fmaxf(kx1, x1);
+    float h = fminf(ky2, y2) - fmaxf(ky1, y1);
+    w = w > 0.0f ? w : 0.0f;
+    h = h > 0.0f ? h : 0.0f;
+    const float inter = w * h;
+    const float iou = inter / (karea + area - inter);
+    return iou > thr;
+}
+
+// one wavefront per image
+__global__ void __launch_bounds__(64) nms_greedy_kernel(const NmsArgs a)
+{
+    extern __shared__ float kb[];   // [max_det][5]: x1, y1, x2, y2, area of kept boxes (class offset applied)
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int no = a.nc + 5;
+    const int cols = (a.mode == 0 && a.nc > 1) ? 7 : 6;
+    int n = a.totals[b];
+    if (n > a.max_nms) n = a.max_nms;
+    if ((long)n > a.cap) n = (int)a.cap;
+    int kept = 0;
+    const unsigned long long* keys = a.keys + (long)b * a.cap;
+    float* out = a.out + (long)b * a.max_det * 7;
+    for (int base = 0; base < n && kept < a.max_det; base += 64) {
+        const int k = base + lane;
+        bool alive = k < n;
+        float b0 = 0, b1 = 0, b2 = 0, b3 = 0, score = 0, c5 = 0, c6 = 0;
+        float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+        if (alive) {
+            const unsigned int ci = (unsigned int)(keys[k] & 0xffffffffull);
+            const float* r = a.cand + ((long)b * a.cap + ci) * 4;
+            score = r[0]; c5 = r[1]; c6 = r[2];
+            const float* p = a.det + ((long)b * a.N + __float_as_int(r[3])) * no;
+            if (a.mode == 0) { b0 = p[0]; b1 = p[1]; b2 = p[2]; b3 = p[3]; }
+            else {
+                const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+                b0 = p[0] - hw; b1 = p[1] - hh; b2 = p[0] + hw; b3 = p[1] + hh;
+            }
+            const float c = a.agnostic ? c5 * 0.0f : c5 * a.max_wh;    // metrics.py:438
+            x1 = b0 + c; y1 = b1 + c; x2 = b2 + c; y2 = b3 + c;
+            area = (x2 - x1) * (y2 - y1);
+        }
+        // against the boxes kept so far
+        for (int t = 0; t < kept; ++t) {
+            if (!__any(alive)) break;
+            const float* q = kb + t * 5;
+            if (alive && iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) alive = false;
+        }
+        // among the 64 lanes, in score order
+        for (int i = 0; i < 64; ++i) {
+            const unsigned long long m = __ballot(alive);
+            if (!((m >> i) & 1ull)) continue;
+            if (kept >= a.max_det) break;
+            const float kx1 = __shfl(x1, i), ky1 = __shfl(y1, i), kx2 = __shfl(x2, i), ky2 = __shfl(y2, i), ka = __shfl(area, i);
+            if (lane == i) {
+                float* q = kb + kept * 5;
+                q[0] = x1; q[1] = y1; q[2] = x2; q[3] = y2; q[4] = area;
+                float* o = out + (long)kept * 7;
+                o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = score; o[5] = c5;
+                o[6] = cols == 7 ? c6 : 0.0f;
+            }
+            ++kept;
+            if (lane > i && alive && iou_gt(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, a.iou)) alive = false;
+        }
+        __syncthreads();   // single wave: orders the LDS writes of kb before the next block's reads
+    }
+    if (lane == 0) a.counts[b] = kept;
+}
+
+static long next_pow2(long v)
+{
+    long p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+size_t nms_workspace_bytes(int B, int N, int nc, int multi_label, long* cap_out)
+{
+    const long cap = next_pow2((long)N * ((multi_label && nc > 1) ? nc : 1));
+    const int nblk = (N + ROWS - 1) / ROWS;
+    if (cap_out) *cap_out = cap;
+    size_t bytes = 0;
+    bytes += ((size_t)B * nblk * sizeof(int) + 255) / 256 * 256;
+    bytes += ((size_t)B * sizeof(int) + 255) / 256 * 256;
+    bytes += (size_t)B * cap * sizeof(unsigned long long);
+    bytes += (size_t)B * cap * 4 * sizeof(float);
+    return bytes;
+}
+
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
+{
+    const int nblk = (a.N + ROWS - 1) / ROWS;
+    hipLaunchKernelGGL(nms_count_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(a.B), dim3(256), 0, s, a, nblk);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
+    hipLaunchKernelGGL(nms_pad_kernel, dim3((unsigned)((a.cap + 255) / 256), a.B), dim3(256), 0, s, a);
+    const unsigned chunks = (unsigned)((a.cap + CHUNK - 1) / CHUNK);
+    hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), 0, s, a, 1, 0L);
+    for (long k = 2L * CHUNK; k <= a.cap; k <<= 1) {
+        for (long j = k >> 1; j >= CHUNK; j >>= 1)
+            hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)((a.cap / 2 + 255) / 256), a.B), dim3(256), 0, s, a, k, j);
+        hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), 0, s, a, 0, k);
+    }
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64), (size_t)a.max_det * 5 * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+}  // namespace sky

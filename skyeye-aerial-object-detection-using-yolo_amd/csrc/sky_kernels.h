@@ -1,0 +1,102 @@
+// Host-side launchers of the gfx950 kernels (one .hip file per family).  Internal to libskyeye_hip.so.
+//
+// Data layout in HBM (DESIGN.md "Layout"): activations are NHWC with an explicit pixel stride `ld` (elements)
+// so that a tensor can be a channel slice of a wider concat buffer; element type T is float (exact mode) or
+// bf16 (production).  Convolution weights are [Cout_pad][Kpad] with K = (ky, kx, cin) contiguous, BatchNorm
+// folded, rows padded to the N tile and K padded to one 128-byte K-step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sky {
+
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+// One fused convolution launch: out = act(conv(in, w) + bias) (+ res), optionally written 2x-upsampled
+// (nearest) or decoded as a detection level.
+struct ConvArgs {
+    const void* in;      // T, NHWC, channel offset already applied
+    const void* w;       // T, [rows][Kpad]
+    const float* bias;   // fp32 [>= ntiles*BN]
+    void* out;           // T (or fp32 when out_f32), NHWC view
+    const void* res;     // optional residual, same geometry as out
+    int B, H, W, Cin, ldi;
+    int Ho, Wo, Cout, ldo, ldr;
+    int ks, stride, pad;
+    int Kpad;            // elements
+    int act;
+    int up2;             // write each output pixel to the 2x2 block of a (2Ho, 2Wo) image
+    int out_f32;
+    int M;               // B*Ho*Wo
+    int ntiles;          // N tiles
+    // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
+    int head;
+    float* raw;          // [B, na, gh, gw, no] fp32
+    float* det;          // [B, det_rows, no] fp32
+    int na, no;
+    long det_rows;       // rows per image over all levels
+    long det_off;        // first row of this level
+    float stride_px;     // max(H_in/gh, W_in/gw)
+    float anchor_wh[16]; // anchors[level][a][w,h] * stride_px
+};
+
+int conv_pick_bn(int cout);                      // N tile chosen for a given Cout
+size_t conv_weight_rows(int cout);               // rows the packed weight / bias must have
+int conv_k_step(int dtype);                      // elements per 128-byte K-step
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s);
+
+// ---- layout / glue kernels (k_misc.hip) ----
+// boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
+// s2d = FocusBlock's space-to-depth (blocks.py:176-181, order TL, BL, TR, BR); scale255 = x/255 (validate.py:238)
+hipError_t launch_import(int dtype, const void* src, int src_u8, int src_nhwc, void* dst, int B, int C, int H, int W,
+                         int Cpad, int ld, int s2d, int scale255, hipStream_t s);
+// engine NHWC T -> caller NCHW fp32
+hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s);
+// MaxPool2d(5, stride 1, pad 2), -inf padding (blocks.py:142-144; 9 = 5o5, 13 = 5o5o5 exactly)
+hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C,
+                           hipStream_t s);
+// F.interpolate(mode='nearest') (detector.py:214,218), generic sizes
+hipError_t launch_upsample(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int Ho,
+                           int Wo, hipStream_t s);
+
+// DetectionHead.process_detections alone (detector.py:88-145): raw [B,na,gh,gw,no] -> det rows of one level
+hipError_t launch_decode(const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
+                         float stride_px, const float* anchor_wh /*host, na*2, already * stride*/, hipStream_t s);
+
+// ---- CBAM (attention.py:11-130) ----
+// partial per-channel sum / max over pixel chunks: part[b][chunk][2][C]
+hipError_t launch_ca_reduce(int dtype, const void* x, int ld, int B, int HW, int C, int nchunk, float* part,
+                            hipStream_t s);
+// finish reduce + shared MLP (no bias, ReLU) + sigmoid -> att[b][C]
+hipError_t launch_ca_mlp(const float* part, int B, int HW, int C, int nchunk, int R, const float* w0, const float* w2,
+                         float* att, hipStream_t s);
+// per-pixel mean / max over channels of (x * att) -> stats[b][p][2]; att may be null (plain SpatialAttention)
+hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, int B, int HW, int C, float* stats,
+                           hipStream_t s);
+// 7x7 conv (2->1, pad 3, no bias) + sigmoid -> gate[b][p]
+hipError_t launch_sa_gate(const float* stats, const float* w, int B, int H, int W, float* gate, hipStream_t s);
+// out = (x * att) * gate   (either factor may be null)
+hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, const float* gate, void* out, int ldo,
+                        int B, int HW, int C, hipStream_t s);
+
+// ---- NMS (k_nms.hip) ----
+struct NmsArgs {
+    const float* det;   // [B, N, no]
+    int B, N, nc;
+    float conf, iou, max_wh;
+    int agnostic, multi_label, max_det, max_nms, mode;
+    int n_classes;
+    int classes[64];
+    float* out;         // [B, max_det, 7]
+    int* counts;        // [B]
+    // workspace
+    int* blk_counts;    // [B, nblk]
+    int* totals;        // [B]
+    unsigned long long* keys;  // [B, cap]
+    float* cand;        // [B, cap, 4]  (score, conf, class, src row as int bits)
+    long cap;           // power of two >= N * (multi_label ? nc : 1)
+};
+size_t nms_workspace_bytes(int B, int N, int nc, int multi_label, long* cap_out);
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
+
+}  // namespace sky

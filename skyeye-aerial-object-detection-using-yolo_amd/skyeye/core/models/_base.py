@@ -1,0 +1,206 @@
+"""Common machinery of the drop-in modules: parameter holders + the bridge to libskyeye_hip.so.
+
+Every class in ``blocks.py`` / ``attention.py`` / ``backbone.py`` / ``detector.py`` keeps the reference's
+constructor signature, attribute names and ``state_dict()`` keys, but its ``forward`` is one call into the HIP
+engine (``sky_forward``).  There is deliberately no PyTorch implementation of the math anywhere in this package:
+without the native library or without a HIP device ``forward`` raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _native as N
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class _Holder(nn.Module):
+    """A module that only owns tensors (same names / shapes as the torch.nn layer it stands for)."""
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError(f"{type(self).__name__} only holds parameters; computation runs inside libskyeye_hip.so "
+                           "through the enclosing SkyEye module")
+
+
+class Conv2dParams(_Holder):
+    """Stands for nn.Conv2d(cin, cout, k, ..., bias=bias) (reference blocks.py:31, detector.py:56-59)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = (kernel_size, kernel_size)
+        self.stride, self.padding = (stride, stride), (padding, padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels * kernel_size * kernel_size)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class BatchNormParams(_Holder):
+    """Stands for nn.BatchNorm2d(ch) in eval mode (eps 1e-5), reference blocks.py:32."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class LinearParams(_Holder):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class LayerNormParams(_Holder):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class Marker(_Holder):
+    """Parameter-free placeholder (nn.SiLU / nn.Identity / nn.ReLU / pooling attributes of the reference)."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.kind = name
+
+    def extra_repr(self):
+        return self.kind
+
+
+# ----------------------------------------------------------------------------- native bridge
+class NativeModule(nn.Module):
+    """Base of every drop-in module: forward() == sky_forward on a planned static graph."""
+
+    _sky_module = None          # key of _native.MODULES
+
+    def __init__(self):
+        super().__init__()
+        self.__dict__["_engines"] = {}      # (precision, device, shapes) -> (Handle, weights_version)
+        self.__dict__["_weights_version"] = 0
+        self.__dict__["_precision"] = None   # None: follow parameter dtype (fp32 -> exact, half/bf16 -> bf16)
+
+    # -- configuration handed to sky_create; subclasses override
+    def _sky_config(self):
+        raise NotImplementedError
+
+    # -- reference API surface that changes weights / precision
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.refresh_weights()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.refresh_weights()
+        return r
+
+    def refresh_weights(self):
+        """Call after editing parameters in place: engines re-pack weights on the next forward."""
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.__dict__["_weights_version"] = m.__dict__.get("_weights_version", 0) + 1
+
+    def set_precision(self, precision):
+        """'fp32' (exact MFMA f32 path) or 'bf16' (production).  None = follow the parameter dtype like the
+        reference's model.half() convention (validate.py:195-197)."""
+        if precision not in (None, "fp32", "bf16"):
+            raise ValueError(precision)
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.__dict__["_precision"] = precision
+        return self
+
+    def half(self):
+        """Reference callers use model.half() for the reduced-precision path (validate.py:195-197, detect.py:107-108).
+        Here that selects the bf16 MFMA engine; the fp32 master weights are kept (bf16 has fp32's exponent range)."""
+        return self.set_precision("bf16")
+
+    def bfloat16(self):
+        return self.set_precision("bf16")
+
+    def float(self):
+        self.set_precision("fp32")
+        return super().float()
+
+    def _resolved_precision(self):
+        if self._precision is not None:
+            return self._precision
+        for p in self.parameters():
+            return "bf16" if p.dtype in (torch.float16, torch.bfloat16) else "fp32"
+        return "fp32"
+
+    def _named_weights(self):
+        out = {}
+        for k, v in self.state_dict().items():
+            if v.dtype == torch.long:
+                continue
+            out[k] = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+        return out
+
+    def expected_state(self):
+        """[(name, shape)] the native engine expects -- must equal the module's own state_dict (tests check)."""
+        h = N.Handle(N.make_config(self._sky_module, **self._sky_config()))
+        try:
+            return h.param_spec()
+        finally:
+            h.close()
+
+    def _engine(self, inputs, extra_cfg=None):
+        prec = self._resolved_precision()
+        dev = inputs[0].device
+        key = (prec, dev.index or 0, tuple(tuple(t.shape) for t in inputs), tuple(sorted((extra_cfg or {}).items())))
+        ent = self._engines.get(key)
+        if ent is not None and ent[1] == self._weights_version:
+            return ent[0]
+        if ent is not None:
+            ent[0].close()
+        if len(self._engines) >= 4:                       # keep a few geometries resident
+            _, (old, _) = self._engines.popitem()
+            old.close()
+        cfg = dict(self._sky_config())
+        cfg.update(extra_cfg or {})
+        h = N.Handle(N.make_config(self._sky_module, dtype=N.SKY_BF16 if prec == "bf16" else N.SKY_F32,
+                                   device=dev.index or 0, **cfg))
+        w = self._named_weights()
+        if w:
+            h.load_weights(w)
+        h.plan([N.buffer_from_tensor(t) for t in inputs])
+        self._engines[key] = (h, self._weights_version)
+        return h
+
+    def _prepare_input(self, t):
+        if not torch.is_tensor(t):
+            raise TypeError("SkyEye modules take torch tensors")
+        if not t.is_cuda:
+            raise N.SkyEyeNativeError("SkyEye HIP engine: input tensor is on the CPU; move it to the MI355X "
+                                      "(x.to('cuda')) -- the engine has no CPU path")
+        if t.dtype in (torch.float16, torch.bfloat16):    # callers that did img.half() (validate.py:237)
+            t = t.float()
+        return t.contiguous()
+
+    def _run(self, inputs, extra_cfg=None):
+        inputs = [self._prepare_input(t) for t in inputs]
+        h = self._engine(inputs, extra_cfg)
+        outs = [torch.empty(s, dtype=torch.float32, device=inputs[0].device) for s in h.output_shapes()]
+        stream = torch.cuda.current_stream(inputs[0].device).cuda_stream
+        h.forward([N.buffer_from_tensor(t) for t in inputs], [N.buffer_from_tensor(t) for t in outs], stream)
+        return outs
+
+    def forward(self, x):
+        return self._run([x])[0]

@@ -1,0 +1,244 @@
+"""Detector models -- drop-in for reference skyeye/core/models/detector.py.
+
+Same classes, constructor arguments, attributes (``cfg``, ``stride``, ``names``, ``backbone``, ``neck``,
+``detection_head``) and return values; the forward pass is the MI355X engine.  The reference's own
+``SkyEyeDetector`` cannot be constructed or run; the wiring fixes adopted here are
+  D1  the neck is built with width scale 1 on the backbone's already-scaled channels (detector.py:165-166,276-279)
+  D2  neck / head widths come from the backbone's real feature channels (backbone.py:139-143 vs :40-42,99)
+  D3  ``_initialize_weights`` skips the missing bias of ``nn.Linear(bias=False)`` (detector.py:339-341)
+  D4  EnhancedSkyEyeDetector's cross-layer attention projects key/value to the query width (detector.py:457-469)
+"""
+import math
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from ._base import BatchNormParams, Conv2dParams, LinearParams, NativeModule
+from .attention import CrossLayerAttention
+from .backbone import SkyEyeBackbone
+from .blocks import ConvolutionBlock, CSPBlock, SPPBlock  # noqa: F401  (re-exported like the reference)
+
+DEFAULT_ANCHORS = [[[10, 13], [16, 30], [33, 23]], [[30, 61], [62, 45], [59, 119]], [[116, 90], [156, 198], [373, 326]]]
+
+
+class DetectionHead(NativeModule):
+    """1x1 prediction convs + box decoding  (reference detector.py:18-145)."""
+    _sky_module = "HEAD"
+
+    def __init__(self, num_classes=80, anchors=None, channels=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_outputs = num_classes + 5
+        self.anchors = anchors if anchors is not None else DEFAULT_ANCHORS
+        self.num_anchors = len(self.anchors[0]) if self.anchors else 3
+        self.num_layers = len(self.anchors) if self.anchors else 3
+        self.grid = [torch.zeros(1)] * self.num_layers
+        self.anchor_grid = [torch.zeros(1)] * self.num_layers
+        if channels is None:
+            channels = [256, 512, 1024]
+        self.channels = list(channels)
+        self.detection_layers = nn.ModuleList(Conv2dParams(ch, self.num_anchors * self.num_outputs, 1, bias=True) for ch in channels)
+
+    def _sky_config(self):
+        return dict(nc=self.num_classes, anchors=self.anchors, level_channels=self.channels, input_h=0, input_w=0)
+
+    def forward(self, feature_maps):
+        """-> list of raw [B, anchors, H, W, outputs] tensors (detector.py:61-86)."""
+        # the decoded tensor the engine also produces is discarded here; strides need a nominal input size
+        gh, gw = feature_maps[0].shape[2:]
+        outs = self._run(list(feature_maps), dict(input_h=int(gh) * 8, input_w=int(gw) * 8))
+        return outs[1:]
+
+    def process_detections(self, outputs, input_shape):
+        """raw levels -> [B, sum(anchors*H*W), outputs] boxes (detector.py:88-145); anchor*stride quirk (D13) kept."""
+        dec = _Decode(self.num_classes, self.anchors)
+        dec.__dict__["_precision"] = "fp32"
+        return dec._run(list(outputs), dict(input_h=int(input_shape[0]), input_w=int(input_shape[1])))[0]
+
+    def detect(self, feature_maps, input_shape):
+        """forward + process_detections in one engine call -> (detections, raw outputs)."""
+        outs = self._run(list(feature_maps), dict(input_h=int(input_shape[0]), input_w=int(input_shape[1])))
+        return outs[0], outs[1:]
+
+
+class _Decode(NativeModule):
+    _sky_module = "DECODE"
+
+    def __init__(self, num_classes, anchors):
+        super().__init__()
+        self._cfg = dict(nc=num_classes, anchors=anchors)
+
+    def _sky_config(self):
+        return self._cfg
+
+
+class FeatureNeck(NativeModule):
+    """Top-down + bottom-up fusion  (reference detector.py:148-231)."""
+    _sky_module = "NECK"
+
+    def __init__(self, in_channels, width_multiple=1.0):
+        super().__init__()
+
+        def scaled_channels(x):
+            return max(round(x * width_multiple), 1)
+
+        if width_multiple != 1.0:
+            raise NotImplementedError("FeatureNeck re-applies width_multiple to already scaled channels in the reference "
+                                      "(detector.py:165-166); only width_multiple=1.0 yields a consistent graph (SURVEY D1)")
+        c3, c4, c5 = in_channels
+        self.lateral_conv5 = ConvolutionBlock(c5, scaled_channels(c4), 1, 1)
+        self.lateral_conv4 = ConvolutionBlock(c4, scaled_channels(c3), 1, 1)
+        self.fpn_conv4 = CSPBlock(scaled_channels(c4) * 2, scaled_channels(c4), num_blocks=3)
+        self.fpn_conv3 = CSPBlock(scaled_channels(c3) * 2, scaled_channels(c3), num_blocks=3)
+        self.downsample3 = ConvolutionBlock(scaled_channels(c3), scaled_channels(c3), 3, 2)
+        self.downsample4 = ConvolutionBlock(scaled_channels(c4), scaled_channels(c4), 3, 2)
+        self.pan_conv4 = CSPBlock(scaled_channels(c3) + scaled_channels(c4), scaled_channels(c4), num_blocks=3)
+        self.pan_conv5 = CSPBlock(scaled_channels(c4) + scaled_channels(c5), scaled_channels(c5), num_blocks=3)
+        self.out_channels = [scaled_channels(c3), scaled_channels(c4), scaled_channels(c5)]
+        self._cfg = dict(level_channels=[c3, c4, c5])
+
+    def _sky_config(self):
+        return self._cfg
+
+    def forward(self, features):
+        return self._run(list(features))
+
+
+class SkyEyeDetector(NativeModule):
+    """SkyEye detector  (reference detector.py:234-371)."""
+    _sky_module = "DETECTOR"
+
+    def __init__(self, cfg="skyeye_s.yaml", channels=3, num_classes=None, anchors=None, ch=None, nc=None):
+        super().__init__()
+        if ch is not None:          # spelling used by train.py:91
+            channels = ch
+        if nc is not None:
+            num_classes = nc
+        if isinstance(cfg, dict):
+            self.cfg = cfg
+        else:
+            cfg_path = Path(cfg)
+            if not cfg_path.exists():   # bare names resolve against the packaged configs
+                cand = Path(__file__).resolve().parents[3] / "configs" / "models" / cfg_path.name
+                if cand.exists():
+                    cfg_path = cand
+            with open(cfg_path, errors="ignore") as f:
+                self.cfg = yaml.safe_load(f)
+        if num_classes and num_classes != self.cfg["nc"]:
+            self.cfg["nc"] = num_classes
+        if anchors:
+            self.cfg["anchors"] = anchors
+        if channels != 3:
+            raise NotImplementedError("FocusBlock(3, ...) is hard-wired in the reference backbone (backbone.py:48)")
+        self.backbone = SkyEyeBackbone(base_channels=self.cfg.get("base_channels", 64),
+                                       depth_multiple=self.cfg.get("depth_multiple", 1.0),
+                                       width_multiple=self.cfg.get("width_multiple", 1.0))
+        in_channels = self.backbone.channels                                     # D2: true channels
+        self.neck = FeatureNeck(in_channels, width_multiple=1.0)                 # D1
+        self.detection_head = DetectionHead(num_classes=self.cfg["nc"], anchors=self.cfg.get("anchors", None),
+                                            channels=self.neck.out_channels)
+        self._initialize_weights()
+        # the reference discovers strides with a dry run on zeros(1, ch, 64, 64) (detector.py:274,291-295)
+        self.stride = torch.tensor([8, 16, 32])
+        self.names = [str(i) for i in range(self.cfg["nc"])]
+        self.pt = True   # attribute read by detect.py:126
+
+    def _sky_config(self):
+        return dict(base_channels=self.cfg.get("base_channels", 64), depth_multiple=float(self.cfg.get("depth_multiple", 1.0)),
+                    width_multiple=float(self.cfg.get("width_multiple", 1.0)), nc=self.cfg["nc"], in_channels=3,
+                    anchors=self.detection_head.anchors)
+
+    def forward(self, x, augment=False, visualize=False):
+        """eval: (detections [B, N, nc+5], [raw_P3, raw_P4, raw_P5]); train: raw list (detector.py:300-324).
+        ``augment`` / ``visualize`` are accepted because the reference's callers pass them (validate.py:245, detect.py:140)."""
+        outs = self._run([x])
+        if not self.training:
+            return outs[0], outs[1:]
+        return outs[1:]
+
+    def warmup(self, imgsz=(1, 3, 640, 640)):
+        """detect.py:126 calls model.warmup(imgsz=...)."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.forward(torch.zeros(*imgsz, device=dev))
+
+    def _initialize_weights(self):
+        """detector.py:326-341 with the D3 guard."""
+        for m in self.modules():
+            if isinstance(m, Conv2dParams):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, BatchNormParams):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, LinearParams):
+                m.weight.data.normal_(0, 0.01)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+        self.refresh_weights()
+
+    def load_from_pretrained(self, weights_path):
+        """detector.py:343-371: accepts {'model': module}, {'state_dict': ...} or a bare state dict; keeps entries whose
+        name and shape match.  torch >= 2.6 defaults to weights_only=True, which refuses pickled modules -- say so."""
+        try:
+            checkpoint = torch.load(weights_path, map_location="cpu", weights_only=True)
+        except Exception as exc:  # noqa: BLE001
+            raise RuntimeError(f"{weights_path}: not loadable with weights_only=True ({exc}); export a plain state dict") from exc
+        if "model" in checkpoint and hasattr(checkpoint["model"], "state_dict"):
+            state_dict = checkpoint["model"].float().state_dict()
+        else:
+            state_dict = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
+        model_state_dict = self.state_dict()
+        filtered = {k: v for k, v in state_dict.items() if k in model_state_dict and v.shape == model_state_dict[k].shape}
+        self.load_state_dict(filtered, strict=False)
+        print(f"Loaded {len(filtered)}/{len(model_state_dict)} layers from {weights_path}")
+        return self
+
+
+def parse_model(model_cfg, in_channels=3):
+    """reference detector.py:374-406."""
+    if isinstance(model_cfg, str):
+        with open(model_cfg, errors="ignore") as f:
+            cfg = yaml.safe_load(f)
+    else:
+        cfg = model_cfg
+    return {"base_channels": cfg.get("base_channels", 64), "depth_multiple": cfg.get("depth_multiple", 1.0),
+            "width_multiple": cfg.get("width_multiple", 1.0), "nc": cfg.get("nc", 80), "in_channels": in_channels,
+            "anchors": cfg.get("anchors", None)}
+
+
+def construct_model(model_cfg, in_channels=3, num_classes=None, anchors=None):
+    """reference detector.py:409-433."""
+    cfg = parse_model(model_cfg, in_channels)
+    if num_classes is not None:
+        cfg["nc"] = num_classes
+    if anchors is not None:
+        cfg["anchors"] = anchors
+    return SkyEyeDetector(cfg, in_channels)
+
+
+def load_model(weights, device=None, cfg="skyeye_s.yaml"):
+    """Counterpart of the undefined ``load_model(weights, device)`` the reference CLIs import (validate.py:184)."""
+    model = SkyEyeDetector(cfg)
+    if weights:
+        model.load_from_pretrained(weights)
+    if device is not None:
+        model.to(device)
+    return model.eval()
+
+
+class EnhancedSkyEyeDetector(SkyEyeDetector):
+    """SkyEyeDetector + cross-layer attention between neck levels  (reference detector.py:436-501, with D4)."""
+    _sky_module = "ENHANCED_DETECTOR"
+
+    def __init__(self, cfg="skyeye_s.yaml", channels=3, num_classes=None, anchors=None):
+        super().__init__(cfg, channels, num_classes, anchors)
+        c3, c4, c5 = self.neck.out_channels
+        self.cross_attention_p5_p4 = CrossLayerAttention(query_channels=c4, key_channels=c5, region_size=2, heads=4)
+        self.cross_attention_p4_p3 = CrossLayerAttention(query_channels=c3, key_channels=c4, region_size=2, heads=4)
+        self.refresh_weights()

@@ -1,0 +1,96 @@
+"""GPU parity, whole graph: SkyEyeDetector.forward through the C ABI against the reference fixtures
+(exact fp32 engine) and the bf16 production engine against the same fixtures (agreement rates)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import DETECTOR_CASES, MODELS, variant_of
+from helpers import build_detector, detector_params
+from parity import close, det_close, level_scales
+from seeded import seeded_scene
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DET_FULL = np.load(os.path.join(G, "detectors_full.npz"))
+DET_SAMPLED = np.load(os.path.join(G, "detectors_sampled.npz"))
+
+CASES = [c for c in DETECTOR_CASES if not c.get("enhanced")]
+_MODELS = {}
+
+
+def model_for(case):
+    v = variant_of(case)
+    if v not in _MODELS:
+        m = build_detector(MODELS[case["model"]], case.get("enhanced", False))
+        m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params(v).items()}, strict=True)
+        _MODELS[v] = m.eval()
+    return _MODELS[v]
+
+
+def run(case, precision, as_uint8=False):
+    m = model_for(case).set_precision(precision)
+    h, w = case["hw"]
+    frames = torch.from_numpy(seeded_scene(case["batch"], h, w, case["seed"])).cuda()
+    x = frames if as_uint8 else frames.float() / 255.0          # validate.py:236-238
+    det, raw = m(x)
+    torch.cuda.synchronize()
+    return det.cpu().numpy(), [r.cpu().numpy() for r in raw]
+
+
+def check_against_fixture(case, det, raw, tol):
+    name = case["name"]
+    scales = level_scales(case["hw"])
+    if case["store"] == "full":
+        det_close(det, DET_FULL[f"{name}.det"], scales, tol)
+        for i, r in enumerate(raw):
+            close(r, DET_FULL[f"{name}.raw{i}"], rtol=5e-5 * tol / 1e-4)
+    else:
+        flat = det.reshape(-1, det.shape[-1])
+        rows = DET_SAMPLED[f"{name}.rows"]
+        det_close(flat[rows], DET_SAMPLED[f"{name}.det_rows"], np.tile(scales, (case["batch"], 1))[rows], tol)
+        for i, r in enumerate(raw):
+            rf = r.reshape(-1, r.shape[-1])
+            close(rf[DET_SAMPLED[f"{name}.raw{i}_rows"]], DET_SAMPLED[f"{name}.raw{i}_vals"], rtol=5e-5 * tol / 1e-4)
+        np.testing.assert_allclose(np.abs(flat.astype(np.float64)).mean(0), DET_SAMPLED[f"{name}.absmean"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_detector_fp32_matches_reference_fixture(case):
+    det, raw = run(case, "fp32")
+    assert det.shape[1] == sum(3 * (case["hw"][0] // s) * (case["hw"][1] // s) for s in (8, 16, 32))
+    check_against_fixture(case, det, raw, 1e-4)
+
+
+def test_uint8_input_equals_float_input():
+    case = CASES[0]
+    d0, r0 = run(case, "fp32")
+    d1, r1 = run(case, "fp32", as_uint8=True)
+    assert np.array_equal(d0, d1)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["store"] == "full"], ids=[c["name"] for c in CASES if c["store"] == "full"])
+def test_detector_bf16_agreement(case):
+    det, raw = run(case, "bf16")
+    ref = DET_FULL[f"{case['name']}.det"]
+    # logits: bf16 activations through ~100 layers; judged relative to the logit range
+    for i, r in enumerate(raw):
+        rr = DET_FULL[f"{case['name']}.raw{i}"]
+        err = np.abs(r - rr).max() / max(1.0, np.abs(rr).max())
+        assert err < 0.15, f"level {i}: bf16 logit error {err:.3f} of range"
+    agree = (det[..., 5:].argmax(-1) == ref[..., 5:].argmax(-1)).mean()
+    obj_err = np.abs(det[..., 4] - ref[..., 4]).max()
+    print(f"{case['name']}: class agreement {agree:.4f}, max |d obj| {obj_err:.4f}")
+    assert agree > 0.9
+    assert obj_err < 0.15
+
+
+def test_train_mode_returns_raw_only():
+    case = CASES[0]
+    m = model_for(case).set_precision("fp32")
+    x = torch.from_numpy(seeded_scene(1, 64, 64, 3)).cuda().float() / 255.0
+    m.train()
+    out = m(x)
+    m.eval()
+    assert isinstance(out, list) and len(out) == 3 and out[0].shape[-1] == 15
