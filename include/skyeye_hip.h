@@ -202,6 +202,10 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
                         void* stream, int iters, int max_ops, float* ms_per_op, double* flops_per_op, int32_t* tag_per_op,
                         int32_t* n_ops);
 
+/* Human-readable description of launch `index` of the planned graph ("conv 3x3 s1 128->128 @80x80 ...") for
+ * profiling reports.  Returns SKY_ERR_INVALID past the last launch. */
+int sky_op_info(const sky_handle* h, int index, char* text, int text_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,7 @@ struct Engine {
     std::vector<void*> owned;   // device allocations to free on re-plan
     char* arena = nullptr;
     size_t arena_bytes = 0;
+    void* zero_page = nullptr;   // 256 bytes of zeros: masked loads of the conv kernel point here
     std::vector<IoInfo> in_info, out_info;
     std::vector<sky_buffer> plan_inputs;
     double flops = 0, act_bytes = 0, weight_bytes = 0;
@@ -138,6 +139,8 @@ struct Engine {
         for (void* p : owned) (void)hipFree(p);
         owned.clear();
         if (arena) (void)hipFree(arena);
+        if (zero_page) (void)hipFree(zero_page);
+        zero_page = nullptr;
         arena = nullptr;
         arena_bytes = 0;
         ops.clear();
@@ -853,12 +856,13 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 memset(&a, 0, sizeof(a));
                 const DevConv& d = e.convs[op.wid];
                 a.in = tv_ptr(e, op.in, ins, n_in, outs, n_out);
-                a.w = d.w; a.bias = d.bias; a.Kpad = d.Kpad;
+                a.w = d.w; a.bias = d.bias; a.Kpad = d.Kpad; a.zero = e.zero_page;
                 a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.Cin = op.cin; a.ldi = op.in.ld;
                 a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.cout;
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.ks / 2;
                 a.act = op.act; a.up2 = op.up2;
                 a.M = op.in.B * op.Ho * op.Wo;
+                { static const int dbg = getenv("SKY_CONV_DBG") ? atoi(getenv("SKY_CONV_DBG")) : 0; a.dbg = dbg; }
                 if (op.head) {
                     a.head = 1;
                     TV r; r.ext = op.raw_ext;
@@ -962,6 +966,8 @@ static void plan(Engine& e, const Geometry& g)
     build(c, g);
     place_buffers(e);
     SKY_HIP(hipMalloc(&e.arena, e.arena_bytes));
+    SKY_HIP(hipMalloc(&e.zero_page, 256));
+    SKY_HIP(hipMemset(e.zero_page, 0, 256));
     for (const Op& op : e.ops) {
         auto bytes = [&](const TV& t) { return t.valid() ? (double)t.B * t.H * t.W * t.C * e.esize() : 0.0; };
         e.act_bytes += bytes(op.in) + bytes(op.out) + bytes(op.res);
@@ -1173,6 +1179,20 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
             if (tag_per_op) tag_per_op[i] = (int)op.kind * 1000 + (op.kind == OP_CONV ? conv_pick_bn(op.cout) : 0);
         }
     });
+}
+
+int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
+{
+    if (!h || !text || index < 0 || index >= (int)h->e.ops.size()) return SKY_ERR_INVALID;
+    static const char* names[] = {"import", "export", "conv", "maxpool5", "upsample", "ca_reduce", "ca_mlp", "sa_stats", "sa_gate", "scale", "decode"};
+    const Op& op = h->e.ops[index];
+    if (op.kind == OP_CONV)
+        snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s tile%d", op.ks, op.ks, op.stride, op.cin, op.cout,
+                 op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
+                 op.head ? " head" : "", conv_pick_bn(op.cout));
+    else
+        snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
+    return SKY_OK;
 }
 
 int sky_plan_stats(const sky_handle* h, double* flops, double* activation_bytes, double* weight_bytes, int32_t* launches)

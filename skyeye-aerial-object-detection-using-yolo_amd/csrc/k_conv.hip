@@ -20,6 +20,7 @@
 #include "sky_kernels.h"
 
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 namespace sky {
 
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
 
     const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
+    const T* __restrict__ zero = reinterpret_cast<const T*>(a.zero);
 
     // ---- loader state: this thread always fetches 16-byte chunk `cc` of rows rbase + i*RPP ----
     const int cc = tid & 7;
@@ -132,19 +134,20 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         const int kx = tap - ky * a.ks;
         const long koff = ((long)ky * a.W + kx) * a.ldi + cidx * EPC;
         const bool tap_ok = tap < taps;
+        // Every load is unconditional: out-of-image taps, rows past M and K padding read a 16-byte block of zeros
+        // instead (pointer select, no branch).  A branch around each load makes hipcc wait vmcnt(0) per load, i.e.
+        // 8 dependent memory round trips per K-step (cdna_hip_programming.md 5, ".s-level traps" (c)).
 #pragma unroll
         for (int i = 0; i < PCH; ++i) {
             const bool ok = tap_ok && (unsigned)(piy[i] + ky) < (unsigned)a.H && (unsigned)(pix[i] + kx) < (unsigned)a.W;
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4_t*>(in + pbase[i] + koff);
-            preg[i] = v;
+            const T* src = (ok && !(a.dbg & 4)) ? in + pbase[i] + koff : zero;
+            preg[i] = *reinterpret_cast<const u32x4_t*>(src);
         }
 #pragma unroll
         for (int j = 0; j < WCH; ++j) {
             const int n = rbase + j * RPP;
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (n < BN) v = *reinterpret_cast<const u32x4_t*>(wgt + (long)(n0 + n) * a.Kpad + (long)kt * (8 * EPC) + cc * EPC);
-            wreg[j] = v;
+            const T* src = (n < BN) ? wgt + (long)(n0 + n) * a.Kpad + (long)kt * (8 * EPC) + cc * EPC : zero;
+            wreg[j] = *reinterpret_cast<const u32x4_t*>(src);
         }
         cidx += 8;
         while (cidx >= cpc) { cidx -= cpc; ++tap; }
@@ -190,10 +193,12 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
 #pragma unroll
             for (int i = 0; i < MF; ++i)
                 pf[i] = *reinterpret_cast<const u32x4_t*>(pb + (wm * MF * 16 + i * 16 + fr) * 128 + chunk);
+            if (!(a.dbg & 8)) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int i = 0; i < MF; ++i) mma_chunk<T>(wf[j], pf[i], acc[j][i]);
+            }
         }
         if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
@@ -250,7 +255,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         const float* src = ot + ml * OP + g * V;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if (e < V) v[e] = act_apply(src[e] + a.bias[n + e], a.act);
+            if (e < V) v[e] = act_apply(src[e] + a.bias[n + e], (a.dbg & 1) ? 0 : a.act);
         if (a.res) {
             if (sizeof(T) == 2) {
                 if (wide) {
@@ -287,6 +292,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             dstep_x = 1;
             dstep_y = 2 * a.Wo;
         }
+        if ((a.dbg & 2) && v[0] != 12345.678f) continue;
         for (int r = 0; r < rep; ++r) {
             const long p = p0 + (r & 1) * dstep_x + (r >> 1) * dstep_y;
             if (a.out_f32 || sizeof(T) == 4) {
@@ -357,6 +363,11 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s)
 {
+    static const bool no_stream = getenv("SKY_NO_STREAM") != nullptr;   // A/B switch for profiling
+    if (a.ks == 1 && !no_stream) {
+        const hipError_t e = launch_conv1x1_stream(dtype, a, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     return dtype == 0 ? launch_t<float>(a, s) : launch_t<__bf16>(a, s);
 }
 

@@ -46,3 +46,11 @@ def level_scales(hw, anchors=None, strides=(8, 16, 32), grids=None):
         for a in lvl:
             rows.append(np.tile(np.asarray([[st, a[0] * st, a[1] * st]], dtype=np.float64), (gh * gw, 1)))
     return np.concatenate(rows, 0)
+
+
+def close(a, b, rtol=2e-5):
+    """dense tensors: max |a - b| <= rtol * max(1, max|b|)"""
+    assert a.shape == b.shape, f"{a.shape} vs {b.shape}"
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+    assert err <= rtol * scale, f"max err {err:.3e} > {rtol * scale:.3e}"

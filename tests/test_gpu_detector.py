@@ -32,8 +32,9 @@ def model_for(case):
 def run(case, precision, as_uint8=False):
     m = model_for(case).set_precision(precision)
     h, w = case["hw"]
-    frames = torch.from_numpy(seeded_scene(case["batch"], h, w, case["seed"])).cuda()
-    x = frames if as_uint8 else frames.float() / 255.0          # validate.py:236-238
+    frames = seeded_scene(case["batch"], h, w, case["seed"])
+    # validate.py:236-238: img.float() / 255 on the CPU path (true division; torch's GPU kernel multiplies by 1/255)
+    x = torch.from_numpy(frames if as_uint8 else frames.astype(np.float32) / np.float32(255.0)).cuda()
     det, raw = m(x)
     torch.cuda.synchronize()
     return det.cpu().numpy(), [r.cpu().numpy() for r in raw]
