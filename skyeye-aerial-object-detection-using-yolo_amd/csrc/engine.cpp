@@ -266,7 +266,7 @@ struct Ctx {
         const int kstep = conv_k_step(e.dtype);
         const int K = taps * cin_store;
         const int Kpad = (K + kstep - 1) / kstep * kstep;
-        const size_t rows = conv_weight_rows(cout);
+        const size_t rows = std::max(conv_weight_rows(cout), (size_t)(cout + 63) / 64 * 64);   // zero rows up to either kernel's N tile
         std::vector<float> packed(rows * Kpad, 0.0f), bias(rows, 0.0f);
         int row0 = 0;
         for (auto& s : srcs) {

@@ -328,7 +328,7 @@ size_t conv_weight_rows(int cout)
     return (size_t)((cout + bn - 1) / bn) * bn;
 }
 
-int conv_k_step(int dtype) { return dtype == 0 ? 32 : 64; }
+int conv_k_step(int dtype) { return dtype == 0 ? 64 : 128; }   // packed K is padded to 256 bytes (one ring slab)
 
 template <typename T, int WM, int WN, int MF, int NF>
 static hipError_t launch_one(const ConvArgs& a, hipStream_t s)
@@ -364,8 +364,8 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s)
 {
     static const bool no_stream = getenv("SKY_NO_STREAM") != nullptr;   // A/B switch for profiling
-    if (a.ks == 1 && !no_stream) {
-        const hipError_t e = launch_conv1x1_stream(dtype, a, s);
+    if (!no_stream) {
+        const hipError_t e = launch_conv_stream(dtype, a, s);
         if (e != hipErrorNotSupported) return e;
     }
     return dtype == 0 ? launch_t<float>(a, s) : launch_t<__bf16>(a, s);

@@ -86,9 +86,50 @@ __global__ void import_kernel(const S* __restrict__ src, int src_nhwc, T* __rest
     }
 }
 
+// Fast path of the detector's stem: NCHW 3-channel image (u8 or fp32) -> space-to-depth NHWC pixel of 12 channels
+// (+ zero padding to Cpad).  One thread per output pixel: 6 two-element loads (rows 2y, 2y+1 of each plane; consecutive
+// threads read consecutive element pairs), whole 16-byte stores.
+template <typename T, typename S>
+__global__ void import_s2d3_kernel(const S* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int Cpad, int ld, int scale255)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % Wo);
+        const long t = p / Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const S* r0 = src + (((long)b * 3 + c) * H + 2 * y) * W + 2 * x;
+            const S* r1 = r0 + W;
+            // patch order TL, BL, TR, BR (blocks.py:176-181): channel = patch * 3 + c
+            float tl = (float)r0[0], tr = (float)r0[1], bl = (float)r1[0], br = (float)r1[1];
+            if (scale255) { tl = tl / 255.0f; tr = tr / 255.0f; bl = bl / 255.0f; br = br / 255.0f; }
+            v[0 + c] = tl; v[3 + c] = bl; v[6 + c] = tr; v[9 + c] = br;
+        }
+        T* o = dst + p * ld;
+        constexpr int N = Vec<T>::N;
+        for (int g = 0; g < Cpad / N; ++g) Vec<T>::store(o + g * N, v + g * N);
+    }
+}
+
 hipError_t launch_import(int dtype, const void* src, int src_u8, int src_nhwc, void* dst, int B, int C, int H, int W,
                          int Cpad, int ld, int s2d, int scale255, hipStream_t s)
 {
+    if (s2d && !src_nhwc && C == 3 && Cpad <= 16 && (W % 2 == 0)) {
+        const long total = (long)B * (H / 2) * (W / 2);
+        const int grid = cap_grid((total + 255) / 256);
+#define SKY_IMPORT3(T, S) \
+    hipLaunchKernelGGL((import_s2d3_kernel<T, S>), dim3(grid), dim3(256), 0, s, (const S*)src, (T*)dst, B, H, W, Cpad, ld, scale255)
+        if (dtype == 0) { if (src_u8) SKY_IMPORT3(float, unsigned char); else SKY_IMPORT3(float, float); }
+        else            { if (src_u8) SKY_IMPORT3(__bf16, unsigned char); else SKY_IMPORT3(__bf16, float); }
+#undef SKY_IMPORT3
+        return hipGetLastError();
+    }
     const long total = (long)B * (s2d ? H / 2 : H) * (s2d ? W / 2 : W) * Cpad;
     const int grid = cap_grid((total + 255) / 256);
 #define SKY_IMPORT(T, S) \

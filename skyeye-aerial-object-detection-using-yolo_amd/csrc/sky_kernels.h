@@ -30,6 +30,7 @@ struct ConvArgs {
     int out_f32;
     int M;               // B*Ho*Wo
     int ntiles;          // N tiles
+    int cpt_shift;       // log2(16-byte chunks per tap) or -1 (streaming kernel)
     int dbg;             // experiment knobs (env SKY_CONV_DBG): 1 no act, 2 no store, 4 no P loads, 8 no MFMA
     // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
     int head;
@@ -46,8 +47,8 @@ int conv_pick_bn(int cout);                      // N tile chosen for a given Co
 size_t conv_weight_rows(int cout);               // rows the packed weight / bias must have
 int conv_k_step(int dtype);                      // elements per 128-byte K-step
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s);
-// streaming 1x1 path (k_conv1x1.hip); hipErrorNotSupported when the shape is not covered
-hipError_t launch_conv1x1_stream(int dtype, const ConvArgs& a, hipStream_t s);
+// streaming path (k_conv_stream.hip): weights resident in LDS; hipErrorNotSupported when the shape is not covered
+hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
