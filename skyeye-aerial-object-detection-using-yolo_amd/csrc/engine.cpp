@@ -862,7 +862,10 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.ks / 2;
                 a.act = op.act; a.up2 = op.up2;
                 a.M = op.in.B * op.Ho * op.Wo;
-                { static const int dbg = getenv("SKY_CONV_DBG") ? atoi(getenv("SKY_CONV_DBG")) : 0; a.dbg = dbg; }
+                {
+                    const double ext = ((double)op.in.B * op.in.H * op.in.W - 1.0) * op.in.ld * e.esize() + (double)op.cin * e.esize();
+                    a.in_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;   // offsets are computed in int32
+                }
                 if (op.head) {
                     a.head = 1;
                     TV r; r.ext = op.raw_ext;

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < PCH; ++i) {
             const bool ok = tap_ok && (unsigned)(piy[i] + ky) < (unsigned)a.H && (unsigned)(pix[i] + kx) < (unsigned)a.W;
-            const T* src = (ok && !(a.dbg & 4)) ? in + pbase[i] + koff : zero;
+            const T* src = ok ? in + pbase[i] + koff : zero;
             preg[i] = *reinterpret_cast<const u32x4_t*>(src);
         }
 #pragma unroll
@@ -193,12 +193,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
 #pragma unroll
             for (int i = 0; i < MF; ++i)
                 pf[i] = *reinterpret_cast<const u32x4_t*>(pb + (wm * MF * 16 + i * 16 + fr) * 128 + chunk);
-            if (!(a.dbg & 8)) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int i = 0; i < MF; ++i) mma_chunk<T>(wf[j], pf[i], acc[j][i]);
-            }
         }
         if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
@@ -255,7 +253,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         const float* src = ot + ml * OP + g * V;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if (e < V) v[e] = act_apply(src[e] + a.bias[n + e], (a.dbg & 1) ? 0 : a.act);
+            if (e < V) v[e] = act_apply(src[e] + a.bias[n + e], a.act);
         if (a.res) {
             if (sizeof(T) == 2) {
                 if (wide) {
@@ -292,7 +290,6 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             dstep_x = 1;
             dstep_y = 2 * a.Wo;
         }
-        if ((a.dbg & 2) && v[0] != 12345.678f) continue;
         for (int r = 0; r < rep; ++r) {
             const long p = p0 + (r & 1) * dstep_x + (r >> 1) * dstep_y;
             if (a.out_f32 || sizeof(T) == 4) {

@@ -1,27 +1,30 @@
-// Streaming convolution for gfx950 (MI355X): the HBM-bound part of the SkyEye graph -- every 1x1 convolution and
-// the 3x3 convolutions whose whole weight tile fits in LDS (Cin <= 64: the stem, stage 1/2 and the 160x160 neck
-// bottlenecks).  For 3x3 the K dimension enumerates (tap, channel): a lane's 16-byte chunk of K belongs to one
-// filter tap and is fetched from the correspondingly shifted input pixel (out-of-image taps read the zero block).
+// Streaming convolution for gfx950 (MI355X): every 1x1 convolution and every 3x3 convolution of the SkyEye graph
+// except the three detection levels (ConvolutionBlock, reference blocks.py:10-41; the residual add of BottleneckBlock,
+// blocks.py:88-90; the nearest-2x upsample + concat of FeatureNeck, detector.py:210-219, as epilogue variants).
 //
-// 48 of the 75 ConvolutionBlocks of skyeye_s (reference blocks.py:10-41; CSP cv1/cv2/cv3, bottleneck cv1, the neck's
-// lateral convs) are 1x1: a GEMM D[cout][pixel] = W[cout][cin] * P[pixel][cin] with K = Cin <= 1024 and a huge M.
-// Their arithmetic intensity (<= 128 FLOP/B at Cin = Cout = 128) is below the MFMA/HBM ridge, so the kernel is
-// built as a byte streamer, not as a tiled GEMM:
-//   * the whole weight tile [N_blk][Cin] (+ bias) is loaded into LDS ONCE per workgroup and stays resident;
-//     workgroups are persistent (one per CU) and walk a contiguous range of pixel tiles
-//   * every wave owns its pixels: the MFMA B operand (pixels) is loaded straight from global memory into
-//     registers in fragment order (16 B per lane), one 256-byte-of-K slab ahead of the MFMAs; pixels are read once
-//     and shared with no other wave, so an LDS round trip would be pure overhead
-//     (cdna_hip_programming.md 5, "glds vs register staging", GEMV row) -- and there is NO barrier in the loop
-//   * weight rows are permuted when read from LDS so that a lane ends up with 8 CONSECUTIVE output channels of its
-//     pixel per pair of accumulator fragments: the epilogue (bias, SiLU, residual, bf16 pack) stores 16-byte
-//     channel vectors straight from registers -- no LDS staging of the output either
-//   * masked loads (pixels past M, K tail) read a zero block instead of branching
-// Also used for the nearest-2x-upsampled lateral convs of FeatureNeck (detector.py:210-219).
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * P[pixel][k], k = (tap, cin).  Most of these layers sit below the
+// MFMA/HBM ridge (1x1 with Cin = Cout = 128 has 128 FLOP/B), so the kernel is organised as a byte streamer:
+//   * PIXELS NEVER TOUCH LDS.  Every wave owns its pixels: the MFMA B operand is fetched from global memory straight
+//     into registers in fragment order (16 bytes per lane through a raw buffer descriptor; a masked lane -- pixel past
+//     M, filter tap outside the image, K tail -- uses offset 0xffffffff and the hardware range check returns zeros),
+//     one 256-byte slab of K ahead of the MFMAs.  A pixel tile is shared with no other wave, so an LDS round trip
+//     would be pure overhead (cdna_hip_programming.md 5, "glds vs register staging", GEMV row).
+//   * WEIGHTS LIVE IN LDS as [slab][cout][256 B], 16-byte chunks XOR-swizzled by the row so that the permuted fragment
+//     reads below are bank-conflict free (checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md).
+//     RING = false: the whole [N_blk][K] tile is loaded once per persistent workgroup and stays resident, no barrier
+//     in the loop.  RING = true (K*N_blk too large): the eight waves walk K in lockstep and the 256-byte weight slabs
+//     stream through a two-stage ring, one barrier per slab.
+//   * weight rows are permuted when read (fragment j, MFMA row r -> channel (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3)) so
+//     that a lane ends up with 8 CONSECUTIVE output channels of its pixel per pair of accumulator fragments: the
+//     epilogue (bias, SiLU, residual, bf16 pack) stores 16-byte channel vectors straight from registers.
+//   * when a filter tap spans a multiple of 64 bytes (UTAP) the tap of a K-step is wave-uniform and its address
+//     arithmetic stays on the scalar unit.
 #include "sky_kernels.h"
 
 #include <hip/hip_bf16.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace sky {
 
@@ -30,10 +33,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 template <typename T>
-struct S1 {
-    static __device__ __forceinline__ void mma(const u32x4_t& wf, const u32x4_t& pf, f32x4_t& acc);
-    static __device__ __forceinline__ float silu(float v);
-};
+struct S1;
 template <>
 struct S1<__bf16> {
     static __device__ __forceinline__ void mma(const u32x4_t& wf, const u32x4_t& pf, f32x4_t& acc)
@@ -54,277 +54,78 @@ struct S1<float> {
     static __device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
 };
 
-static constexpr int S1_WAVES = 8;
+static constexpr int SW = 8;        // waves per workgroup
+static constexpr int SLAB = 256;    // bytes of K per slab (4 MFMA K-steps of 64 bytes)
+
+__device__ __forceinline__ int wswz(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
 
 // MF: 16-pixel fragments per wave tile, NF: 16-channel fragments (N_blk = 16*NF output channels per workgroup)
-template <typename T, int KS, int MF, int NF>
-__global__ void __launch_bounds__(S1_WAVES * 64) conv_stream_kernel(const ConvArgs a)
+// KT: 64-byte K-steps in the LAST slab of K (1, 2 or 4) -- a template parameter so that both loop bodies are branch-free
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT>
+__global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 {
     static_assert(NF % 2 == 0, "pairs of fragments form one 8-channel vector");
     constexpr int NB = NF * 16;
     constexpr int TPX = MF * 16;
+    constexpr int BUF = NB * SLAB;                 // one slab of weights: [NB rows][256 B]
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int Cb = a.Cin * (int)sizeof(T);      // bytes of one filter tap per pixel
-    const int cpt = Cb >> 4;                    // 16-byte chunks per tap
-    const int Kb = KS * KS * Cb;                // bytes of K per output pixel
-    const int ksteps = (Kb + 63) >> 6;          // 64-byte K-steps (one MFMA group each)
-    const int Kl = ksteps << 6;                 // K bytes kept per weight row in LDS (tail is zero padding)
-    const int pitch = Kl + 16;                  // LDS row pitch of the resident weight tile
+    const int Cb = a.Cin * (int)sizeof(T);         // bytes of one filter tap per pixel
+    const int cpt = Cb >> 4;                       // 16-byte chunks per tap
+    const int Kb = KS * KS * Cb;                   // bytes of K per output pixel
+    const int nslab = (Kb + SLAB - 1) / SLAB;
     const int n0 = blockIdx.y * NB;
     const char* __restrict__ in = reinterpret_cast<const char*>(a.in);
-    const char* __restrict__ zero = reinterpret_cast<const char*>(a.zero);
-    float* lbias = reinterpret_cast<float*>(smem + NB * pitch);
-
-    // ---- resident weights + bias ----
-    {
-        const char* wsrc = reinterpret_cast<const char*>(a.w);
-        const int cpr = Kl >> 4;                // 16-byte chunks per row
-        for (int idx = tid; idx < NB * cpr; idx += S1_WAVES * 64) {
-            const int row = idx / cpr, c = idx - row * cpr;
-            *reinterpret_cast<u32x4_t*>(smem + row * pitch + c * 16) =
-                *reinterpret_cast<const u32x4_t*>(wsrc + (long)(n0 + row) * a.Kpad * (long)sizeof(T) + c * 16);
-        }
-        for (int i = tid; i < NB; i += S1_WAVES * 64) lbias[i] = a.bias[n0 + i];
-    }
-    __syncthreads();
-
-    // ---- this wave's tiles: contiguous range per workgroup, waves interleaved inside it ----
-    const int ntiles = (a.M + TPX - 1) / TPX;
-    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int t_end = min(ntiles, (int)(blockIdx.x + 1) * per);
-    int t = blockIdx.x * per + wave;
-    if (t >= t_end) return;
-    const int nslab = (ksteps + 3) >> 2;
-    int sl = 0;
-
-    // LDS row of fragment j, MFMA row r: channel (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3)
-    const int wrow0 = (fr >> 2) * 8 + (fr & 3);
-
-    f32x4_t acc[NF][MF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-        for (int i = 0; i < MF; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    u32x4_t pA[MF][4], pB[MF][4];
-
-    // load-side pixel state of the tile currently being fetched (decoded once per tile, not per slab)
-    long lbase[MF];
-    int liy[MF], lix[MF];
-    auto decode_tile = [&](int tt) {
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = tt * TPX + i * 16 + fr;
-            if (m >= a.M) { lbase[i] = 0; liy[i] = lix[i] = -(1 << 24); continue; }
-            if (KS == 1) {
-                lbase[i] = (long)m * a.ldi * (long)sizeof(T);
-                liy[i] = lix[i] = 0;
-            } else {
-                const int ox = m % a.Wo;
-                const int q = m / a.Wo;
-                const int oy = q % a.Ho;
-                const int b = q / a.Ho;
-                liy[i] = oy * a.stride - a.pad;
-                lix[i] = ox * a.stride - a.pad;
-                lbase[i] = ((long)(b * a.H + liy[i]) * a.W + lix[i]) * a.ldi * (long)sizeof(T);
-            }
-        }
-    };
-    auto load_slab = [&](u32x4_t (&dst)[MF][4], int ss) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int c = (ss * 4 + kk) * 4 + fq;          // this lane's 16-byte chunk of K
-            int tap = 0, w = c, ky = 0, kx = 0;
-            if (KS != 1) {
-                tap = a.cpt_shift >= 0 ? (c >> a.cpt_shift) : (c / cpt);
-                w = c - tap * cpt;
-                ky = (tap * 11) >> 5;
-                kx = tap - ky * 3;
-            }
-            const bool kok = KS == 1 ? (c < cpt) : (tap < KS * KS);
-            const long koff = ((long)ky * a.W + kx) * a.ldi * (long)sizeof(T) + w * 16;
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const bool ok = kok && (unsigned)(liy[i] + ky) < (unsigned)a.H && (unsigned)(lix[i] + kx) < (unsigned)a.W;
-                const char* src = ok ? in + lbase[i] + koff : zero;
-                dst[i][kk] = *reinterpret_cast<const u32x4_t*>(src);
-            }
-        }
-    };
-    auto compute = [&](const u32x4_t (&cur)[MF][4], int ss) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ks = ss * 4 + kk;
-            if (ks < ksteps) {
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const int row = (j >> 1) * 32 + (j & 1) * 4 + wrow0;
-                    const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(smem + row * pitch + ks * 64 + fq * 16);
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) S1<T>::mma(wf, cur[i][kk], acc[j][i]);
-                }
-            }
-        }
-    };
-    auto epilogue = [&](int tt) {
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = tt * TPX + i * 16 + fr;
-            if (m < a.M) {
-                long p0 = m;
-                int rep = 1;
-                long step_y = 0;
-                if (a.up2) {
-                    const int x = m % a.Wo;
-                    const int q = m / a.Wo;
-                    const int y = q % a.Ho;
-                    const int b = q / a.Ho;
-                    p0 = ((long)(b * 2 * a.Ho + 2 * y)) * (2 * a.Wo) + 2 * x;
-                    rep = 4;
-                    step_y = 2 * a.Wo;
-                }
-#pragma unroll
-                for (int s = 0; s < NF / 2; ++s) {
-                    const int nl = s * 32 + fq * 8;
-                    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
-                    const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[2 * s][i][e] + b0[e];
-                        v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
-                    }
-                    if (a.act == ACT_SILU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = S1<T>::silu(v[e]);
-                    } else if (a.act == ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                    }
-                    const int n = n0 + nl;
-                    if (a.res) {
-                        if (sizeof(T) == 2) {
-                            const u32x4_t r = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.res) + (long)m * a.ldr + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[2 * e] += __uint_as_float(r[e] << 16);
-                                v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
-                            }
-                        } else {
-                            const float* rp = reinterpret_cast<const float*>(a.res) + (long)m * a.ldr + n;
-                            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rp), r1 = *reinterpret_cast<const f32x4_t*>(rp + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-                        }
-                    }
-                    for (int r = 0; r < rep; ++r) {
-                        const long p = p0 + (r & 1) + (r >> 1) * step_y;
-                        if (sizeof(T) == 2) {
-                            u32x4_t o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                                o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-                            }
-                            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.out) + p * a.ldo + n) = o;
-                        } else {
-                            float* op = reinterpret_cast<float*>(a.out) + p * a.ldo + n;
-                            *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4_t*>(op + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    // one pipeline step: prefetch the next slab into `nxt`, consume `cur`; false when the wave is done
-    auto step = [&](u32x4_t (&cur)[MF][4], u32x4_t (&nxt)[MF][4]) -> bool {
-        int nsl = sl + 1, nt = t;
-        if (nsl == nslab) { nsl = 0; nt = t + S1_WAVES; }
-        const bool more = nt < t_end;
-        if (more) {
-            if (nsl == 0) decode_tile(nt);
-            load_slab(nxt, nsl);
-        }
-        compute(cur, sl);
-        if (sl == nslab - 1) epilogue(t);
-        t = nt;
-        sl = nsl;
-        return more;
-    };
-
-    decode_tile(t);
-    load_slab(pA, 0);
-    for (;;) {
-        if (!step(pA, pB)) break;
-        if (!step(pB, pA)) break;
-    }
-}
-
-template <typename T, int KS, int MF, int NF>
-__global__ void __launch_bounds__(S1_WAVES * 64) conv_ring_kernel(const ConvArgs a)
-{
-    static_assert(NF % 2 == 0, "pairs of fragments form one 8-channel vector");
-    constexpr int NB = NF * 16;
-    constexpr int TPX = MF * 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int Cb = a.Cin * (int)sizeof(T);      // bytes of one filter tap per pixel
-    const int cpt = Cb >> 4;                    // 16-byte chunks per tap
-    const int Kb = KS * KS * Cb;                // bytes of K per output pixel
-    const int ksteps = (Kb + 63) >> 6;          // 64-byte K-steps (one MFMA group each)
-    constexpr int SLAB = 256;                   // bytes of K per weight row and ring stage
-    constexpr int BUF = NB * SLAB;              // one ring stage: [NB rows][256 B], 16-byte chunks XOR-swizzled by row
-    const int n0 = blockIdx.y * NB;
-    const char* __restrict__ in = reinterpret_cast<const char*>(a.in);
-    const char* __restrict__ zero = reinterpret_cast<const char*>(a.zero);
-    float* lbias = reinterpret_cast<float*>(smem + 2 * BUF);
     const char* __restrict__ wsrc = reinterpret_cast<const char*>(a.w);
     const long wpitch = (long)a.Kpad * (long)sizeof(T);
+    float* lbias = reinterpret_cast<float*>(smem + (RING ? 2 : nslab) * BUF);
 
-    // ---- weight slab staging: every thread moves WCH 16-byte chunks global -> registers -> LDS ----
-    constexpr int WCH = NB * 16 / (S1_WAVES * 64);
-    static_assert(NB * 16 % (S1_WAVES * 64) == 0, "weight slab must split evenly over the workgroup");
+    // ---- weight staging ----
+    constexpr int WCH = (NB * 16 + SW * 64 - 1) / (SW * 64);    // 16-byte chunks per thread per slab
     u32x4_t wreg[WCH];
-    auto wswz = [](int row) { return (row & 3) | (((row >> 3) & 3) << 2); };   // conflict-free for the fragment reads below
     auto load_w = [&](int ss) {
 #pragma unroll
         for (int k = 0; k < WCH; ++k) {
-            const int idx = tid + k * (S1_WAVES * 64);
+            const int idx = tid + k * (SW * 64);
             const int row = idx >> 4, c = idx & 15;
-            wreg[k] = *reinterpret_cast<const u32x4_t*>(wsrc + (long)(n0 + row) * wpitch + (long)ss * SLAB + c * 16);
+            if (NB * 16 % (SW * 64) == 0 || idx < NB * 16)
+                wreg[k] = *reinterpret_cast<const u32x4_t*>(wsrc + (long)(n0 + row) * wpitch + (long)ss * SLAB + c * 16);
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < WCH; ++k) {
-            const int idx = tid + k * (S1_WAVES * 64);
+            const int idx = tid + k * (SW * 64);
             const int row = idx >> 4, c = idx & 15;
-            *reinterpret_cast<u32x4_t*>(smem + buf * BUF + row * SLAB + ((c ^ wswz(row)) << 4)) = wreg[k];
+            if (NB * 16 % (SW * 64) == 0 || idx < NB * 16)
+                *reinterpret_cast<u32x4_t*>(smem + buf * BUF + row * SLAB + ((c ^ wswz(row)) << 4)) = wreg[k];
         }
     };
-    for (int i = tid; i < NB; i += S1_WAVES * 64) lbias[i] = a.bias[n0 + i];
+    for (int i = tid; i < NB; i += SW * 64) lbias[i] = a.bias[n0 + i];
 
-    // ---- tiles: the workgroup walks its range 8 tiles (one per wave) at a time, all waves in K lockstep ----
+    // ---- tile schedule ----
     const int ntiles = (a.M + TPX - 1) / TPX;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int t_begin = blockIdx.x * per;
     const int t_end = min(ntiles, t_begin + per);
-    if (t_begin >= t_end) return;                               // uniform per workgroup
-    const int rounds = (t_end - t_begin + S1_WAVES - 1) / S1_WAVES;
-    const int nslab = (Kb + SLAB - 1) / SLAB;
-    int t = t_begin + wave;                                     // tiles past t_end decode as all-masked pixels
+    if (t_begin >= t_end) return;                                   // uniform per workgroup
+    int t = t_begin + wave;                                         // then t += SW
     int sl = 0;
+
+    if (!RING) {                                                    // resident weights: all slabs once
+        for (int ss = 0; ss < nslab; ++ss) {
+            load_w(ss);
+            store_w(ss);
+        }
+        __syncthreads();
+        if (t >= t_end) return;                                     // no barrier after this point
+    }
 
     // LDS row of fragment j, MFMA row r: channel (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3)
     const int wrow0 = (fr >> 2) * 8 + (fr & 3);
+    const int wsw0 = wswz(wrow0);            // rows of different j differ only in bits 2 and 5+, which wswz ignores
 
     f32x4_t acc[NF][MF];
 #pragma unroll
@@ -334,63 +135,85 @@ __global__ void __launch_bounds__(S1_WAVES * 64) conv_ring_kernel(const ConvArgs
 
     u32x4_t pA[MF][4], pB[MF][4];
 
-    // load-side pixel state of the tile currently being fetched (decoded once per tile, not per slab)
-    long lbase[MF];
-    int liy[MF], lix[MF];
+    // load-side pixel state of the tile being fetched (decoded once per tile): 32-bit byte offset of the pixel's
+    // top-left tap and a 9-bit "tap is inside the image" mask
+    int lvo[MF], okm[MF];
     auto decode_tile = [&](int tt) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int m = tt * TPX + i * 16 + fr;
-            if (m >= a.M || tt >= t_end) { lbase[i] = 0; liy[i] = lix[i] = -(1 << 24); continue; }
+            if (m >= a.M || tt >= t_end) { lvo[i] = 0; okm[i] = 0; continue; }
             if (KS == 1) {
-                lbase[i] = (long)m * a.ldi * (long)sizeof(T);
-                liy[i] = lix[i] = 0;
+                lvo[i] = m * a.ldi * (int)sizeof(T);
+                okm[i] = 1;
             } else {
                 const int ox = m % a.Wo;
                 const int q = m / a.Wo;
                 const int oy = q % a.Ho;
                 const int b = q / a.Ho;
-                liy[i] = oy * a.stride - a.pad;
-                lix[i] = ox * a.stride - a.pad;
-                lbase[i] = ((long)(b * a.H + liy[i]) * a.W + lix[i]) * a.ldi * (long)sizeof(T);
+                const int iy = oy * a.stride - a.pad, ix = ox * a.stride - a.pad;
+                lvo[i] = ((b * a.H + iy) * a.W + ix) * a.ldi * (int)sizeof(T);
+                int mask = 0;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        if ((unsigned)(iy + ky) < (unsigned)a.H && (unsigned)(ix + kx) < (unsigned)a.W) mask |= 1 << (ky * 3 + kx);
+                okm[i] = mask;
             }
         }
     };
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in), 0, (int)a.in_bytes, 0x00020000);
     auto load_slab = [&](u32x4_t (&dst)[MF][4], int ss) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int c = (ss * 4 + kk) * 4 + fq;          // this lane's 16-byte chunk of K
-            int tap = 0, w = c, ky = 0, kx = 0;
+            const int c0 = (ss * 4 + kk) * 4;                 // first 16-byte chunk of this K-step (wave-uniform)
+            const int c = UTAP ? c0 : c0 + fq;
+            int tap = 0, w = c;
             if (KS != 1) {
                 tap = a.cpt_shift >= 0 ? (c >> a.cpt_shift) : (c / cpt);
                 w = c - tap * cpt;
-                ky = (tap * 11) >> 5;
-                kx = tap - ky * 3;
             }
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
             const bool kok = KS == 1 ? (c < cpt) : (tap < KS * KS);
-            const long koff = ((long)ky * a.W + kx) * a.ldi * (long)sizeof(T) + w * 16;
+            const int koff = (ky * a.W + kx) * a.ldi * (int)sizeof(T) + w * 16 + (UTAP ? fq * 16 : 0);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
-                const bool ok = kok && (unsigned)(liy[i] + ky) < (unsigned)a.H && (unsigned)(lix[i] + kx) < (unsigned)a.W;
-                const char* src = ok ? in + lbase[i] + koff : zero;
-                dst[i][kk] = *reinterpret_cast<const u32x4_t*>(src);
+                const bool ok = kok && ((okm[i] >> tap) & 1);
+                dst[i][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? lvo[i] + koff : -1, 0, 0);
             }
         }
     };
-    auto compute = [&](const u32x4_t (&cur)[MF][4], int ss, int buf) {
+    // NKK MFMA K-steps of one slab; `wb` = LDS offset of the slab's weights.
+    // Software pipeline over G = NKK * NF/2 groups (K-step kk, fragment pair sp): the two weight fragments of group
+    // g+2 are read from LDS before the 2*MF MFMAs of group g issue, so LDS latency hides behind two groups of matrix
+    // work while only three pairs (24 VGPRs) are live.  sched_barrier pins that order.
+    auto compute_n = [&](const u32x4_t (&cur)[MF][4], int wb, auto nkk_tag) {
+        constexpr int NKK = decltype(nkk_tag)::value;
+        const char* base = smem + wb + wrow0 * SLAB;
+        constexpr int G = NKK * (NF / 2);
+        u32x4_t wq[3][2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ks = ss * 4 + kk;
-            if (ks < ksteps) {
+        for (int g = 0; g < G + 2; ++g) {
+            if (g < G) {
+                const int kk = g / (NF / 2), sp = g % (NF / 2);
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const int row = (j >> 1) * 32 + (j & 1) * 4 + wrow0;
-                    const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(smem + buf * BUF + row * SLAB + (((kk * 4 + fq) ^ wswz(row)) << 4));
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) S1<T>::mma(wf, cur[i][kk], acc[j][i]);
-                }
+                for (int h = 0; h < 2; ++h)
+                    wq[g % 3][h] = *reinterpret_cast<const u32x4_t*>(base + (sp * 32 + h * 4) * SLAB + (((kk * 4 + fq) ^ wsw0) << 4));
             }
+            if (g >= 2) {
+                const int gg = g - 2, kk = gg / (NF / 2), sp = gg % (NF / 2);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) S1<T>::mma(wq[gg % 3][h], cur[i][kk], acc[2 * sp + h][i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto compute = [&](const u32x4_t (&cur)[MF][4], int wb, bool last) {
+        if (KT == 4 || !last) compute_n(cur, wb, std::integral_constant<int, 4>());
+        else compute_n(cur, wb, std::integral_constant<int, KT>());
     };
     auto epilogue = [&](int tt) {
 #pragma unroll
@@ -427,22 +250,25 @@ __global__ void __launch_bounds__(S1_WAVES * 64) conv_ring_kernel(const ConvArgs
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     }
-                    const int n = n0 + nl;
                     if (a.res) {
+                        const char* rp = reinterpret_cast<const char*>(a.res) + ((long)m * a.ldr + n0 + nl) * (long)sizeof(T);
+                        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(rp);
                         if (sizeof(T) == 2) {
-                            const u32x4_t r = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.res) + (long)m * a.ldr + n);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                v[2 * e] += __uint_as_float(r[e] << 16);
-                                v[2 * e + 1] += __uint_as_float(r[e] & 0xffff0000u);
+                                v[2 * e] += __uint_as_float(r0[e] << 16);
+                                v[2 * e + 1] += __uint_as_float(r0[e] & 0xffff0000u);
                             }
                         } else {
-                            const float* rp = reinterpret_cast<const float*>(a.res) + (long)m * a.ldr + n;
-                            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rp), r1 = *reinterpret_cast<const f32x4_t*>(rp + 4);
+                            const u32x4_t r1 = *reinterpret_cast<const u32x4_t*>(rp + 16);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] += __uint_as_float(r0[e]);
+                                v[4 + e] += __uint_as_float(r1[e]);
+                            }
                         }
                     }
+                    const int n = n0 + nl;
                     for (int r = 0; r < rep; ++r) {
                         const long p = p0 + (r & 1) + (r >> 1) * step_y;
                         if (sizeof(T) == 2) {
@@ -465,29 +291,39 @@ __global__ void __launch_bounds__(S1_WAVES * 64) conv_ring_kernel(const ConvArgs
             for (int j = 0; j < NF; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // prologue: first weight slab into stage 0, first pixel slab into registers
-    load_w(0);
+
+    // ---- pipeline ----
+    int it = 0;
+    int total = 0;
+    if (RING) {
+        const int rounds = (t_end - t_begin + SW - 1) / SW;
+        total = rounds * nslab;
+        load_w(0);
+    }
     decode_tile(t);
     load_slab(pA, 0);
-    store_w(0);
-    __syncthreads();
-
-    const int total = rounds * nslab;
-    int it = 0;
-    // one pipeline step: prefetch the next pixel slab (own registers) and weight slab (other LDS stage), consume `cur`
+    if (RING) {
+        store_w(0);
+        __syncthreads();
+    }
+    // one step: prefetch the next pixel slab (own registers) and, with RING, the next weight slab (other LDS stage);
+    // consume `cur`.  Returns false when this wave (RING: the workgroup) is done.
     auto step = [&](u32x4_t (&cur)[MF][4], u32x4_t (&nxt)[MF][4]) -> bool {
         int nsl = sl + 1, nt = t;
-        if (nsl == nslab) { nsl = 0; nt = t + S1_WAVES; }
-        const bool more = it + 1 < total;                       // uniform per workgroup
-        if (more) {
-            load_w(nsl);
-            if (nsl == 0) decode_tile(nt);
-            load_slab(nxt, nsl);
-        }
-        compute(cur, sl, it & 1);
+        if (nsl == nslab) { nsl = 0; nt = t + SW; }
+        const bool more = RING ? (it + 1 < total) : (nt < t_end);
+        // The prefetch is issued UNCONDITIONALLY (past the end it is fully masked / re-reads a valid weight slab).
+        // Under `if (more)` hipcc must assume the path without the new loads and then waits for the CURRENT slab with
+        // vmcnt(7..0) instead of vmcnt(19..12): every slab would stall on the loads issued a few cycles earlier.
+        if (RING) load_w(nsl);
+        if (nsl == 0) decode_tile(nt);
+        load_slab(nxt, nsl);
+        compute(cur, RING ? (it & 1) * BUF : sl * BUF, sl == nslab - 1);
         if (sl == nslab - 1 && t < t_end) epilogue(t);
-        if (more) store_w((it + 1) & 1);
-        __syncthreads();
+        if (RING) {
+            if (more) store_w((it + 1) & 1);
+            __syncthreads();
+        }
         t = nt;
         sl = nsl;
         ++it;
@@ -500,26 +336,46 @@ __global__ void __launch_bounds__(S1_WAVES * 64) conv_ring_kernel(const ConvArgs
 }
 
 // ------------------------------------------------------------------------------------------------ host
-static int stream_pick_nf(int dtype, const ConvArgs& a)
+static constexpr size_t LDS_BUDGET = 150 * 1024;
+
+struct StreamPlan {
+    int nf = 0;        // 0: not supported
+    bool ring = false;
+};
+
+static StreamPlan stream_plan(int dtype, const ConvArgs& a)
 {
+    StreamPlan p;
     const int esz = dtype == 0 ? 4 : 2;
     const long Cb = (long)a.Cin * esz;
-    if ((a.ks != 1 && a.ks != 3) || a.head || a.out_f32) return 0;   // detection levels stay on the implicit-GEMM kernel
-    if (a.ks == 1 && a.stride != 1) return 0;
-    if (Cb % 16 != 0) return 0;
-    const long Kl = (a.ks * a.ks * Cb + 63) / 64 * 64;
-    for (int nf : {8, 4, 2}) {
+    if ((a.ks != 1 && a.ks != 3) || a.head || a.out_f32) return p;       // detection levels stay on the implicit-GEMM kernel
+    if (a.ks == 1 && a.stride != 1) return p;
+    if (Cb % 16 != 0 || a.in_bytes == 0) return p;
+    const long Kb = (long)a.ks * a.ks * Cb;
+    const long nslab = (Kb + SLAB - 1) / SLAB;
+    if ((long)a.Kpad * esz < nslab * SLAB) return p;                       // packed rows must cover whole slabs
+    static const bool no_ring = getenv("SKY_NO_RING") != nullptr;
+    const bool ring_ok = !no_ring && a.Cout % 128 == 0;
+    int fallback = 0;
+    for (int nf : {8, 4, 2}) {                                             // resident weights
         const int nb = nf * 16;
         if (a.Cout % nb != 0) continue;
-        if ((long)nb * (Kl + 16) + nb * 4 > 144 * 1024) continue;
-        // a 3x3 workgroup re-reads its pixels once per N tile: only worth it when one or two tiles cover Cout
-        if (a.ks == 3 && a.Cout / nb > 2) return 0;
-        return nf;
+        if ((size_t)nb * nslab * SLAB + nb * 4 > LDS_BUDGET) continue;
+        // every N tile re-reads the pixels: resident weights only pay when one or two tiles cover Cout
+        if (a.Cout / nb > 2) { if (a.ks == 1 && !fallback) fallback = nf; continue; }
+        p.nf = nf;
+        return p;
     }
-    return 0;
+    if (ring_ok) {                                                         // weights stream through a two-stage ring
+        p.nf = 8;
+        p.ring = true;
+    } else {
+        p.nf = fallback;
+    }
+    return p;
 }
 
-template <typename T, int KS, int MF, int NF>
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT>
 static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, TPX = MF * 16;
@@ -528,57 +384,62 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     a.cpt_shift = -1;
     for (int sh = 0; sh < 16; ++sh)
         if ((1 << sh) == cpt) a.cpt_shift = sh;
-    const size_t Kl = ((size_t)KS * KS * a.Cin * sizeof(T) + 63) / 64 * 64;
-    if ((size_t)a.Kpad * sizeof(T) < Kl) return hipErrorInvalidValue;    // packed rows must cover the padded K
-    const size_t lds = (size_t)NB * (Kl + 16) + NB * 4;
+    const size_t Kb = (size_t)KS * KS * a.Cin * sizeof(T);
+    const size_t nslab = (Kb + SLAB - 1) / SLAB;
+    const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + NB * 4;
     static size_t attr_lds = 0;
-    auto kern = conv_stream_kernel<T, KS, MF, NF>;
+    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT>;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_lds = lds;
     }
     const int ntiles = (a.M + TPX - 1) / TPX;
-    int gx = (ntiles + S1_WAVES - 1) / S1_WAVES;
+    int gx = (ntiles + SW - 1) / SW;
     if (gx > n_cu) gx = n_cu;
-    hipLaunchKernelGGL(kern, dim3(gx, (a.Cout + NB - 1) / NB), dim3(S1_WAVES * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(gx, a.Cout / NB), dim3(SW * 64), lds, s, a);
     return hipGetLastError();
 }
 
-template <typename T, int KS>
-static hipError_t stream_dispatch(int nf, const ConvArgs& a, hipStream_t s, int n_cu)
+template <typename T, int KS, int KT>
+static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs& a, hipStream_t s, int n_cu)
 {
-    switch (nf) {
-        case 8: return stream_launch<T, KS, 2, 8>(a, s, n_cu);
-        case 4: return stream_launch<T, KS, 4, 4>(a, s, n_cu);
-        default: return stream_launch<T, KS, 4, 2>(a, s, n_cu);
+    if (!utap) {   // narrow inputs (the stem): per-lane tap, only built for the 32-channel tile
+        if (KS == 3 && !p.ring && p.nf == 2) return stream_launch<T, 3, 4, 2, false, false, KT>(a, s, n_cu);
+        return hipErrorNotSupported;
+    }
+    if (p.ring) return KT == 4 ? stream_launch<T, KS, 2, 8, true, true, 4>(a, s, n_cu) : hipErrorNotSupported;
+    switch (p.nf) {
+        case 8:
+            if (KT == 4) return stream_launch<T, KS, 2, 8, false, true, 4>(a, s, n_cu);
+            [[fallthrough]];   // two loop bodies + 128 channels spill: use two 64-channel tiles instead
+        case 4: return stream_launch<T, KS, 2, 4, false, true, KT>(a, s, n_cu);
+        default: return stream_launch<T, KS, 4, 2, false, true, KT>(a, s, n_cu);
     }
 }
 
-template <typename T, int KS, int MF, int NF>
-static hipError_t ring_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
+template <typename T>
+static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipStream_t s, int n_cu)
 {
-    constexpr int NB = NF * 16, TPX = MF * 16;
-    ConvArgs a = a0;
-    const int cpt = a.Cin * (int)sizeof(T) / 16;
-    a.cpt_shift = -1;
-    for (int sh = 0; sh < 16; ++sh)
-        if ((1 << sh) == cpt) a.cpt_shift = sh;
-    const size_t Kb = (size_t)KS * KS * a.Cin * sizeof(T);
-    if ((size_t)a.Kpad * sizeof(T) < (Kb + 255) / 256 * 256) return hipErrorInvalidValue;   // rows must cover whole slabs
-    const size_t lds = (size_t)2 * NB * 256 + NB * 4;
-    static bool attr = false;
-    auto kern = conv_ring_kernel<T, KS, MF, NF>;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr = true;
+    const int Cb = a.Cin * (int)sizeof(T);
+    const bool utap = ((Cb / 16) & 3) == 0;
+    const int Kb = a.ks * a.ks * Cb;
+    const int nslab = (Kb + SLAB - 1) / SLAB;
+    const int kt = ((Kb - (nslab - 1) * SLAB) + 63) >> 6;
+    if (a.ks == 1) {
+        switch (kt) {
+            case 4: return stream_dispatch<T, 1, 4>(p, utap, a, s, n_cu);
+            case 2: return stream_dispatch<T, 1, 2>(p, utap, a, s, n_cu);
+            case 1: return stream_dispatch<T, 1, 1>(p, utap, a, s, n_cu);
+            default: return hipErrorNotSupported;
+        }
     }
-    const int ntiles = (a.M + TPX - 1) / TPX;
-    int gx = (ntiles + S1_WAVES - 1) / S1_WAVES;
-    if (gx > n_cu) gx = n_cu;
-    hipLaunchKernelGGL(kern, dim3(gx, a.Cout / NB), dim3(S1_WAVES * 64), lds, s, a);
-    return hipGetLastError();
+    switch (kt) {
+        case 4: return stream_dispatch<T, 3, 4>(p, utap, a, s, n_cu);
+        case 2: return stream_dispatch<T, 3, 2>(p, utap, a, s, n_cu);
+        case 1: return stream_dispatch<T, 3, 1>(p, utap, a, s, n_cu);
+        default: return hipErrorNotSupported;
+    }
 }
 
 // returns hipErrorNotSupported when the shape is not covered (caller falls back to the implicit-GEMM kernel)
@@ -591,18 +452,9 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s)
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int nf = stream_pick_nf(dtype, a);
-    static const bool no_ring = getenv("SKY_NO_RING") != nullptr;
-    if (nf == 0) {
-        // weights too large to stay resident: stream them through a two-stage LDS ring, 128 output channels per workgroup
-        const int esz = dtype == 0 ? 4 : 2;
-        if (no_ring || (a.ks != 1 && a.ks != 3) || a.head || a.out_f32 || (a.ks == 1 && a.stride != 1)) return hipErrorNotSupported;
-        if ((a.Cin * esz) % 16 != 0 || a.Cout % 128 != 0) return hipErrorNotSupported;
-        if (dtype == 0) return a.ks == 1 ? ring_launch<float, 1, 2, 8>(a, s, n_cu) : ring_launch<float, 3, 2, 8>(a, s, n_cu);
-        return a.ks == 1 ? ring_launch<__bf16, 1, 2, 8>(a, s, n_cu) : ring_launch<__bf16, 3, 2, 8>(a, s, n_cu);
-    }
-    if (dtype == 0) return a.ks == 1 ? stream_dispatch<float, 1>(nf, a, s, n_cu) : stream_dispatch<float, 3>(nf, a, s, n_cu);
-    return a.ks == 1 ? stream_dispatch<__bf16, 1>(nf, a, s, n_cu) : stream_dispatch<__bf16, 3>(nf, a, s, n_cu);
+    const StreamPlan p = stream_plan(dtype, a);
+    if (p.nf == 0) return hipErrorNotSupported;
+    return dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu) : stream_dispatch_t<__bf16>(p, a, s, n_cu);
 }
 
 }  // namespace sky

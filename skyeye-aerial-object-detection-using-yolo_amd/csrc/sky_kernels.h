@@ -31,7 +31,7 @@ struct ConvArgs {
     int M;               // B*Ho*Wo
     int ntiles;          // N tiles
     int cpt_shift;       // log2(16-byte chunks per tap) or -1 (streaming kernel)
-    int dbg;             // experiment knobs (env SKY_CONV_DBG): 1 no act, 2 no store, 4 no P loads, 8 no MFMA
+    unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)
     // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
     int head;
     float* raw;          // [B, na, gh, gw, no] fp32
