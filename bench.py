@@ -157,19 +157,26 @@ def main():
         for ms, fl, tag in prof:
             e = by.setdefault(tag, [0.0, 0.0, 0])
             e[0] += ms; e[1] += fl; e[2] += 1
-        conv = {t: v for t, v in by.items() if t // 1000 == 2}      # OP_CONV
+        conv = {t: v for t, v in by.items() if t // 10000 == 2}      # OP_CONV
         dom_tag, dom = max(conv.items(), key=lambda kv: kv[1][0])
+        variant = dom_tag % 10000
+        tname = "bf16" if a.precision == "bf16" else "float"
+        kname = (f"conv_stream_kernel<{tname}> weight-ring, N_blk {variant % 1000}" if variant >= 3000 else
+                 f"conv_stream_kernel<{tname}> resident weights, N_blk {variant % 1000}" if variant >= 2000 else
+                 f"conv_igemm_kernel<{tname}> N tile {variant % 1000}")
         conv_ms = sum(v[0] for v in conv.values()); conv_fl = sum(v[1] for v in conv.values())
         tot_ms = sum(v[0] for v in by.values())
         peak = PEAK_TFLOPS[a.precision]
         ach = dom[1] / (dom[0] * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "mfma", "kernel": f"conv_igemm_kernel<{'bf16' if a.precision == 'bf16' else 'float'}> N-tile {dom_tag % 1000}",
+            "bound": "mfma", "kernel": kname,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "launches_per_step": dom[2], "avg_launch_ms": round(dom[0] / dom[2], 4),
             "flops_per_launch": dom[1] / dom[2],
             "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "conv_ms_per_step": round(conv_ms, 3),
             "graph_ms_per_step": round(tot_ms, 3), "graph_launches": len(prof),
+            "conv_variants": {str(t % 10000): {"launches": v[2], "ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                              for t, v in sorted(conv.items())},
             "graph_gflop_per_frame": round(sum(v[1] for v in by.values()) / B / 1e9, 2),
             "baseline_gflop_per_frame": GFLOP_PER_FRAME.get((a.model, S)),
             "end_to_end_tflops": round(fps / world * sum(v[1] for v in by.values()) / B / 1e12, 2),

@@ -197,7 +197,8 @@ int sky_time_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int 
 
 /* Per-launch timing of the planned graph (bench.py's roofline leg): runs `iters` forwards with a hipEvent recorded
  * on `stream` after every launch and returns, per launch, the mean milliseconds, the algorithmic FLOPs, and a tag
- * (op kind * 1000 + N-tile of the convolution kernel variant, 0 for non-GEMM launches). */
+ * (op kind * 10000 + convolution kernel variant: 1000+N tile = implicit-GEMM tile kernel, 2000+N_blk = streaming kernel
+ * with LDS-resident weights, 3000+N_blk = streaming kernel with the weight ring; 0 for non-GEMM launches). */
 int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs,
                         void* stream, int iters, int max_ops, float* ms_per_op, double* flops_per_op, int32_t* tag_per_op,
                         int32_t* n_ops);

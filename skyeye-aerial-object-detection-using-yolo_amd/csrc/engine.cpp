@@ -88,6 +88,7 @@ struct Op {
     int f0 = -1, f1 = -1;  // fp32 device weights (index into Engine::fweights)
     int Ho = 0, Wo = 0;
     double flops = 0;
+    int variant = 0;       // which conv kernel ran last (launch_conv)
 };
 
 struct DevConv {
@@ -839,7 +840,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     const sky_config& cf = e.cfg;
     int op_index = 0;
     if (marks) SKY_HIP(hipEventRecord(marks[0], s));
-    for (const Op& op : e.ops) {
+    for (Op& op : e.ops) {
         switch (op.kind) {
             case OP_IMPORT: {
                 const sky_buffer& src = ins[op.in.ext];
@@ -881,7 +882,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     a.ldo = op.out.ld;
                     if (op.res.valid()) { a.res = tv_ptr(e, op.res, ins, n_in, outs, n_out); a.ldr = op.res.ld; }
                 }
-                SKY_HIP(launch_conv(e.dtype, a, s));
+                SKY_HIP(launch_conv(e.dtype, a, s, &op.variant));
                 break;
             }
             case OP_MAXPOOL5:
@@ -1179,7 +1180,7 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
             const Op& op = h->e.ops[i];
             if (ms_per_op) ms_per_op[i] = (float)(acc[i] / std::max(iters, 1));
             if (flops_per_op) flops_per_op[i] = op.flops;
-            if (tag_per_op) tag_per_op[i] = (int)op.kind * 1000 + (op.kind == OP_CONV ? conv_pick_bn(op.cout) : 0);
+            if (tag_per_op) tag_per_op[i] = (int)op.kind * 10000 + (op.kind == OP_CONV ? op.variant : 0);
         }
     });
 }
@@ -1190,9 +1191,9 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     static const char* names[] = {"import", "export", "conv", "maxpool5", "upsample", "ca_reduce", "ca_mlp", "sa_stats", "sa_gate", "scale", "decode"};
     const Op& op = h->e.ops[index];
     if (op.kind == OP_CONV)
-        snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s tile%d", op.ks, op.ks, op.stride, op.cin, op.cout,
+        snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
-                 op.head ? " head" : "", conv_pick_bn(op.cout));
+                 op.head ? " head" : "", op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     return SKY_OK;

@@ -358,13 +358,14 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
     }
 }
 
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s)
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant)
 {
     static const bool no_stream = getenv("SKY_NO_STREAM") != nullptr;   // A/B switch for profiling
     if (!no_stream) {
-        const hipError_t e = launch_conv_stream(dtype, a, s);
+        const hipError_t e = launch_conv_stream(dtype, a, s, variant);
         if (e != hipErrorNotSupported) return e;
     }
+    if (variant) *variant = 1000 + conv_pick_bn(a.Cout);
     return dtype == 0 ? launch_t<float>(a, s) : launch_t<__bf16>(a, s);
 }
 

@@ -443,7 +443,7 @@ static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipS
 }
 
 // returns hipErrorNotSupported when the shape is not covered (caller falls back to the implicit-GEMM kernel)
-hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s)
+hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant)
 {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -454,7 +454,9 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s)
     }
     const StreamPlan p = stream_plan(dtype, a);
     if (p.nf == 0) return hipErrorNotSupported;
-    return dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu) : stream_dispatch_t<__bf16>(p, a, s, n_cu);
+    const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu) : stream_dispatch_t<__bf16>(p, a, s, n_cu);
+    if (e == hipSuccess && variant) *variant = (p.ring ? 3000 : 2000) + p.nf * 16;
+    return e;
 }
 
 }  // namespace sky

@@ -46,9 +46,11 @@ struct ConvArgs {
 int conv_pick_bn(int cout);                      // N tile chosen for a given Cout
 size_t conv_weight_rows(int cout);               // rows the packed weight / bias must have
 int conv_k_step(int dtype);                      // elements per 128-byte K-step
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s);
+// *variant (optional) receives which kernel ran: 1000 + N tile = implicit-GEMM tile kernel, 2000 + N_blk = streaming kernel
+// with resident weights, 3000 + N_blk = streaming kernel with the weight ring
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
 // streaming path (k_conv_stream.hip): weights resident in LDS; hipErrorNotSupported when the shape is not covered
-hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
