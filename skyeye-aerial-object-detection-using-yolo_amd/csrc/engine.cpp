@@ -68,7 +68,7 @@ struct TV {
     bool valid() const { return buf >= 0 || ext >= 0; }
 };
 
-enum OpKind { OP_IMPORT, OP_EXPORT, OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE, OP_CA_REDUCE, OP_CA_MLP, OP_SA_STATS, OP_SA_GATE, OP_SCALE, OP_DECODE };
+enum OpKind { OP_IMPORT, OP_EXPORT, OP_CONV, OP_MAXPOOL5, OP_UPSAMPLE, OP_CA_REDUCE, OP_CA_MLP, OP_SA_STATS, OP_SA_GATE, OP_SCALE, OP_DECODE, OP_LAYERNORM, OP_ATTENTION, OP_CLA, OP_EXPORT_TOKENS };
 
 struct Op {
     OpKind kind;
@@ -89,6 +89,10 @@ struct Op {
     int Ho = 0, Wo = 0;
     double flops = 0;
     int variant = 0;       // which conv kernel ran last (launch_conv)
+    // attention
+    int heads = 0, ntok = 0, nW = 0, mask_ext = -1, v_off = 0, force_nhwc = 0;
+    float scale = 1.0f, r2 = 1.0f;
+    TV in2;                // second activation input (CLA key/value tensor)
 };
 
 struct DevConv {
@@ -226,7 +230,7 @@ struct Ctx {
     void push(Op op)
     {
         if (!emit) return;
-        touch(op.in.buf); touch(op.out.buf); touch(op.res.buf);
+        touch(op.in.buf); touch(op.out.buf); touch(op.res.buf); touch(op.in2.buf);
         touch(op.s0); touch(op.s1); touch(op.s2);
         e.flops += op.flops;
         e.ops.push_back(op);
@@ -470,6 +474,129 @@ static TV cbam(Ctx& c, const std::string& p, const TV& x, int C, bool channel, b
     return y;
 }
 
+// nn.Linear / 1x1 nn.Conv2d with bias on NHWC tokens (a token is a pixel): same GEMM as a 1x1 convolution
+static TV linear(Ctx& c, const std::string& wname, const std::string& bname, const TV& x, int cin, int cout, int act, bool conv4d,
+                 const TV* out_into = nullptr, const TV* res = nullptr)
+{
+    if (conv4d) c.need(wname, {cout, cin, 1, 1}); else c.need(wname, {cout, cin});
+    if (!bname.empty()) c.need(bname, {cout});
+    c.check_channels(cin, (wname + " in_features").c_str());
+    c.check_channels(cout, (wname + " out_features").c_str());
+    if (x.C != cin) throw Error(SKY_ERR_SHAPE, wname + ": input has " + std::to_string(x.C) + " channels, expected " + std::to_string(cin));
+    TV y = out_into ? *out_into : c.new_tensor(x.B, x.H, x.W, cout);
+    Op op;
+    op.kind = OP_CONV;
+    op.in = x; op.out = y;
+    if (res) op.res = *res;
+    op.cin = cin; op.cout = cout; op.ks = 1; op.stride = 1; op.act = act;
+    op.Ho = x.H; op.Wo = x.W;
+    op.wid = c.pack_conv({{wname, "", bname}}, cin, cin, 1);
+    op.flops = 2.0 * x.B * x.H * x.W * (double)cout * cin;
+    c.push(op);
+    return y;
+}
+
+static TV layernorm(Ctx& c, const std::string& p, const TV& x, int C)
+{
+    c.need(p + "weight", {C});
+    c.need(p + "bias", {C});
+    TV y = c.new_tensor(x.B, x.H, x.W, C);
+    Op op;
+    op.kind = OP_LAYERNORM;
+    op.in = x; op.out = y;
+    if (c.emit) { op.f0 = c.upload_f32(c.W(p + "weight").data); op.f1 = c.upload_f32(c.W(p + "bias").data); }
+    c.push(op);
+    return y;
+}
+
+static TV attention_core(Ctx& c, const TV& qkv, int C, int heads, float scale, int bias_f, int mask_ext, int nW)
+{
+    const int d = C / heads;
+    if (C % heads || (d != 8 && d != 16 && d != 32 && d != 64 && d != 128))
+        throw Error(SKY_ERR_INVALID, "attention head dimension " + std::to_string(d) + " not supported (8, 16, 32, 64, 128)");
+    TV y = c.new_tensor(qkv.B, qkv.H, qkv.W, C);
+    Op op;
+    op.kind = OP_ATTENTION;
+    op.in = qkv; op.out = y;
+    op.heads = heads; op.ntok = qkv.H * qkv.W; op.scale = scale; op.f0 = bias_f; op.mask_ext = mask_ext; op.nW = nW;
+    op.flops = 4.0 * qkv.B * (double)op.ntok * op.ntok * C;
+    c.push(op);
+    return y;
+}
+
+// TransformerLayer.forward, eval mode (attention.py:282-309): x + MHA(LN1(x)); then + FFN(LN2(.)), FFN = Linear-ReLU-Linear
+static TV transformer(Ctx& c, const std::string& p, const TV& x, int C, int heads, int ff)
+{
+    TV n1 = layernorm(c, p + "norm1.", x, C);
+    TV qkv = linear(c, p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", n1, C, 3 * C, ACT_NONE, false);
+    TV att = attention_core(c, qkv, C, heads, 1.0f / std::sqrt((float)(C / heads)), -1, -1, 1);
+    TV x1 = linear(c, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", att, C, C, ACT_NONE, false, nullptr, &x);
+    TV n2 = layernorm(c, p + "norm2.", x1, C);
+    TV f = linear(c, p + "feedforward.0.weight", p + "feedforward.0.bias", n2, C, ff, ACT_RELU, false);
+    return linear(c, p + "feedforward.3.weight", p + "feedforward.3.bias", f, ff, C, ACT_NONE, false, nullptr, &x1);
+}
+
+// WindowedSelfAttention.forward (attention.py:358-399); x is [B_, N = ws*ws, C] (carried as B_ x 1 x N x C)
+static TV windowed_attention(Ctx& c, const std::string& p, const TV& x, int C, int ws, int heads, int mask_ext, int nW)
+{
+    const int N = ws * ws, T = (2 * ws - 1) * (2 * ws - 1);
+    c.need(p + "relative_position_bias_table", {T, heads});
+    if (x.H * x.W != N) throw Error(SKY_ERR_SHAPE, p + ": tokens per window must equal window_size^2");
+    TV qkv = linear(c, p + "qkv.weight", p + "qkv.bias", x, C, 3 * C, ACT_NONE, false);
+    int bias_f = -1;
+    if (c.emit) {   // bias[h][i][j] = table[index[i][j]][h], index as attention.py:342-353 (meshgrid 'ij')
+        const std::vector<float>& tab = c.W(p + "relative_position_bias_table").data;
+        std::vector<float> bias((size_t)heads * N * N);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                const int dy = i / ws - j / ws + ws - 1, dx = i % ws - j % ws + ws - 1;
+                const int idx = dy * (2 * ws - 1) + dx;
+                for (int h = 0; h < heads; ++h) bias[((size_t)h * N + i) * N + j] = tab[(size_t)idx * heads + h];
+            }
+        bias_f = c.upload_f32(bias);
+    }
+    const int d = C / heads;
+    TV att = attention_core(c, qkv, C, heads, 1.0f / std::sqrt((float)d), bias_f, mask_ext, nW);
+    return linear(c, p + "proj.weight", p + "proj.bias", att, C, C, ACT_NONE, false);
+}
+
+// CrossLayerAttention.forward (attention.py:174-241), closed form; D4: key/value projections map Ck -> Cq
+static TV cross_layer_attention(Ctx& c, const std::string& p, const TV& q, const TV& k, int Cq, int Ck, int Cout, int heads, int region,
+                                const TV* res = nullptr, const TV* out_into = nullptr)
+{
+    if (Cq % heads) throw Error(SKY_ERR_INVALID, p + ": query_channels must be divisible by heads");
+    TV Q = linear(c, p + "query_projection.weight", p + "query_projection.bias", q, Cq, Cq, ACT_NONE, true);
+    // key | value projections as one GEMM with N = 2*Cq
+    c.need(p + "key_projection.weight", {Cq, Ck, 1, 1});
+    c.need(p + "key_projection.bias", {Cq});
+    c.need(p + "value_projection.weight", {Cq, Ck, 1, 1});
+    c.need(p + "value_projection.bias", {Cq});
+    c.check_channels(Ck, (p + "key_channels").c_str());
+    if (k.C != Ck) throw Error(SKY_ERR_SHAPE, p + ": key tensor channel mismatch");
+    TV KV = c.new_tensor(k.B, k.H, k.W, 2 * Cq);
+    {
+        Op op;
+        op.kind = OP_CONV;
+        op.in = k; op.out = KV;
+        op.cin = Ck; op.cout = 2 * Cq; op.ks = 1; op.stride = 1; op.act = ACT_NONE;
+        op.Ho = k.H; op.Wo = k.W;
+        op.wid = c.pack_conv({{p + "key_projection.weight", "", p + "key_projection.bias"}, {p + "value_projection.weight", "", p + "value_projection.bias"}}, Ck, Ck, 1);
+        op.flops = 2.0 * k.B * k.H * k.W * (double)(2 * Cq) * Ck;
+        c.push(op);
+    }
+    TV A = c.new_tensor(q.B, q.H, q.W, Cq);
+    Op op;
+    op.kind = OP_CLA;
+    op.in = Q; op.in2 = KV; op.out = A;
+    op.heads = heads; op.v_off = Cq;
+    op.scale = 1.0f / std::sqrt((float)Cq);                       // attention.py:159: 1/sqrt(query_channels), not head dim
+    op.r2 = (float)(region * region);
+    op.s0 = c.emit ? c.new_buf((size_t)q.B * q.H * q.W * heads * 4) : -1;
+    op.flops = 2.0 * q.B * q.H * q.W * (double)Cq * 9;
+    c.push(op);
+    return linear(c, p + "output_projection.weight", p + "output_projection.bias", A, Cq, Cout, ACT_NONE, true, out_into, res);
+}
+
 static int scaled_channels(int x, float wm) { return std::max((int)std::lround(std::nearbyint((double)x * wm)), 1); }
 // Python's round() is banker's rounding; nearbyint under the default FE_TONEAREST mode matches it.
 static int scaled_depth(int x, float dm) { return std::max((int)std::nearbyint((double)x * dm), 1); }
@@ -493,11 +620,12 @@ static TV import_focus(Ctx& c, int ext, int B, int C, int H, int W)
     return t;
 }
 
-static TV import_plain(Ctx& c, int ext, int B, int C, int H, int W, const TV* into = nullptr)
+static TV import_plain(Ctx& c, int ext, int B, int C, int H, int W, const TV* into = nullptr, bool tokens = false)
 {
     TV t = into ? *into : c.new_tensor(B, H, W, C);
     Op op;
     op.kind = OP_IMPORT;
+    op.force_nhwc = tokens ? 1 : 0;     // [B_, N, C] token tensors are channel-last at the boundary
     op.in.ext = ext; op.out = t; op.s2d = 0; op.src_c = C; op.src_h = H; op.src_w = W;
     c.push(op);
     return t;
@@ -513,6 +641,21 @@ static void export_nchw(Ctx& c, const TV& t, int ext_out)
         IoInfo io;
         io.ndim = 4;
         io.shape[0] = t.B; io.shape[1] = t.C; io.shape[2] = t.H; io.shape[3] = t.W;
+        if ((int)c.e.out_info.size() <= ext_out) c.e.out_info.resize(ext_out + 1);
+        c.e.out_info[ext_out] = io;
+    }
+}
+
+static void export_tokens(Ctx& c, const TV& t, int ext_out)
+{
+    Op op;
+    op.kind = OP_EXPORT_TOKENS;
+    op.in = t; op.out.ext = 16 + ext_out;
+    c.push(op);
+    if (c.emit) {
+        IoInfo io;
+        io.ndim = 3;
+        io.shape[0] = t.B; io.shape[1] = (int64_t)t.H * t.W; io.shape[2] = t.C;
         if ((int)c.e.out_info.size() <= ext_out) c.e.out_info.resize(ext_out + 1);
         c.e.out_info[ext_out] = io;
     }
@@ -735,7 +878,8 @@ static void build(Ctx& c, const Geometry& g)
             head(c, "", f, nl, cf.nc, cf.num_anchors, cf.anchors, cf.input_h, cf.input_w, 0);
             break;
         }
-        case SKY_MOD_DETECTOR: {
+        case SKY_MOD_DETECTOR:
+        case SKY_MOD_ENHANCED_DETECTOR: {
             expect_inputs(g, 1, "SkyEyeDetector");
             const int B = dim(0, 0), C = dim(0, 1), H = dim(0, 2), W = dim(0, 3);
             if (H % 32 || W % 32) throw Error(SKY_ERR_SHAPE, "SkyEyeDetector: H and W must be multiples of the maximum stride 32 (check_img_size, general.py:248-268)");
@@ -746,7 +890,41 @@ static void build(Ctx& c, const Geometry& g)
             backbone(c, "backbone.backbone.", 0, B, C, H, W, cf.base_channels, cf.depth_multiple, wm, &n.p3, &n.p4, &n.p5);
             TV out[3];
             neck(c, "neck.", n, c3, c4, c5, out);                                        // D1: neck width scale = 1
+            if (cf.module == SKY_MOD_ENHANCED_DETECTOR) {                                // detector.py:485-491 with D4
+                TV p4e = cross_layer_attention(c, "cross_attention_p5_p4.", out[1], out[2], c4, c5, c4, 4, 2, &out[1]);
+                TV p3e = cross_layer_attention(c, "cross_attention_p4_p3.", out[0], p4e, c3, c4, c3, 4, 2, &out[0]);
+                out[0] = p3e;
+                out[1] = p4e;
+            }
             head(c, "detection_head.", out, 3, cf.nc, cf.num_anchors, cf.anchors, H, W, 0);
+            break;
+        }
+        case SKY_MOD_CROSS_LAYER_ATTENTION: {
+            expect_inputs(g, 2, "CrossLayerAttention");
+            TV q = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            TV k = import_plain(c, 1, dim(1, 0), dim(1, 1), dim(1, 2), dim(1, 3));
+            export_nchw(c, cross_layer_attention(c, "", q, k, cf.c_in, cf.key_channels > 0 ? cf.key_channels : cf.c_in,
+                                                 cf.c_out > 0 ? cf.c_out : cf.c_in, cf.heads > 0 ? cf.heads : 4,
+                                                 cf.region_size > 0 ? cf.region_size : 2), 0);
+            break;
+        }
+        case SKY_MOD_TRANSFORMER_LAYER: {
+            expect_inputs(g, 1, "TransformerLayer");
+            TV x = import_plain(c, 0, dim(0, 0), dim(0, 1), dim(0, 2), dim(0, 3));
+            export_nchw(c, transformer(c, "", x, cf.c_in, cf.heads, cf.c_out > 0 ? cf.c_out : 4 * cf.c_in), 0);
+            break;
+        }
+        case SKY_MOD_WINDOWED_ATTENTION: {
+            if (g.n < 1 || g.n > 2 || g.ndim[0] != 3) throw Error(SKY_ERR_SHAPE, "WindowedSelfAttention: x must be [B*nW, N, C] (+ optional mask [nW, N, N])");
+            const int Bw = dim(0, 0), N = dim(0, 1), C = dim(0, 2);
+            if (C != cf.c_in) throw Error(SKY_ERR_SHAPE, "WindowedSelfAttention: channel mismatch");
+            int nW = 1;
+            if (g.n == 2) {
+                if (g.ndim[1] != 3 || dim(1, 1) != N || dim(1, 2) != N || Bw % dim(1, 0)) throw Error(SKY_ERR_SHAPE, "WindowedSelfAttention: mask must be [nW, N, N] with B_ % nW == 0");
+                nW = dim(1, 0);
+            }
+            TV x = import_plain(c, 0, Bw, C, 1, N, nullptr, true);
+            export_tokens(c, windowed_attention(c, "", x, C, cf.window_size, cf.heads, g.n == 2 ? 1 : -1, nW), 0);
             break;
         }
         case SKY_MOD_DECODE: {
@@ -844,7 +1022,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
         switch (op.kind) {
             case OP_IMPORT: {
                 const sky_buffer& src = ins[op.in.ext];
-                SKY_HIP(launch_import(e.dtype, src.data, src.dtype == SKY_IO_U8, src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                SKY_HIP(launch_import(e.dtype, src.data, src.dtype == SKY_IO_U8, op.force_nhwc || src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                       op.out.B, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld, op.s2d, src.dtype == SKY_IO_U8, s));
                 break;
             }
@@ -908,6 +1086,24 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
             case OP_SA_GATE:
                 SKY_HIP(launch_sa_gate((const float*)buf_ptr(e, op.s0), e.fweights[op.f0], op.in.B, op.in.H, op.in.W, (float*)buf_ptr(e, op.s1), s));
                 break;
+            case OP_LAYERNORM:
+                SKY_HIP(launch_layernorm(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                         op.out.ld, e.fweights[op.f0], e.fweights[op.f1], (long)op.in.B * op.in.H * op.in.W, op.in.C, s));
+                break;
+            case OP_ATTENTION:
+                SKY_HIP(launch_attention(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                         op.out.ld, op.in.B, op.ntok, op.out.C, op.heads, op.scale, op.f0 >= 0 ? e.fweights[op.f0] : nullptr,
+                                         op.mask_ext >= 0 ? (const float*)ins[op.mask_ext].data : nullptr, op.nW, s));
+                break;
+            case OP_CLA:
+                SKY_HIP(launch_cla(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.in2, ins, n_in, outs, n_out),
+                                   op.in2.ld, op.v_off, (float*)buf_ptr(e, op.s0), tv_ptr(e, op.out, ins, n_in, outs, n_out), op.out.ld, op.in.B,
+                                   op.in.H, op.in.W, op.in2.H, op.in2.W, op.out.C, op.heads, op.scale, op.r2, s));
+                break;
+            case OP_EXPORT_TOKENS:
+                SKY_HIP(launch_export_tokens(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (float*)tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                             (long)op.in.B * op.in.H * op.in.W, op.in.C, s));
+                break;
             case OP_DECODE: {
                 float awh[16];
                 for (int k = 0; k < cf.num_anchors * 2; ++k) awh[k] = cf.anchors[op.level * cf.num_anchors * 2 + k] * op.stride_px;
@@ -954,6 +1150,10 @@ static void collect_spec(Engine& e)
             g.n = 1; set(0, 1, cf.c_in > 0 ? cf.c_in : 16, 8, 8); break;   // SpatialAttention() has no channel argument
         case SKY_MOD_DECODE: case SKY_MOD_UTILITY:
             return;   // no parameters
+        case SKY_MOD_CROSS_LAYER_ATTENTION:
+            g.n = 2; set(0, 1, cf.c_in, 8, 8); set(1, 1, cf.key_channels > 0 ? cf.key_channels : cf.c_in, 4, 4); break;
+        case SKY_MOD_WINDOWED_ATTENTION:
+            g.n = 1; g.ndim[0] = 3; g.shape[0][0] = 1; g.shape[0][1] = (int64_t)cf.window_size * cf.window_size; g.shape[0][2] = cf.c_in; break;
         default:
             g.n = 1; set(0, 1, cf.c_in, 8, 8); break;
     }
@@ -1188,7 +1388,7 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
 int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
 {
     if (!h || !text || index < 0 || index >= (int)h->e.ops.size()) return SKY_ERR_INVALID;
-    static const char* names[] = {"import", "export", "conv", "maxpool5", "upsample", "ca_reduce", "ca_mlp", "sa_stats", "sa_gate", "scale", "decode"};
+    static const char* names[] = {"import", "export", "conv", "maxpool5", "upsample", "ca_reduce", "ca_mlp", "sa_stats", "sa_gate", "scale", "decode", "layernorm", "attention", "cla", "export_tokens"};
     const Op& op = h->e.ops[index];
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,

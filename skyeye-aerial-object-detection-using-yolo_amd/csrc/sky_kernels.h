@@ -86,6 +86,17 @@ hipError_t launch_sa_gate(const float* stats, const float* w, int B, int H, int 
 hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, const float* gate, void* out, int ldo,
                         int B, int HW, int C, hipStream_t s);
 
+// ---- attention side (k_attn.hip) ----
+hipError_t launch_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, const float* g, const float* b, long tokens, int C,
+                            hipStream_t s);
+// qkv [G, N, 3C] -> out [G, N, C]; bias [heads, N, N] and mask [nW, N, N] optional (fp32)
+hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale,
+                            const float* bias, const float* mask, int nW, hipStream_t s);
+// CrossLayerAttention core: q [B,H,W,C], kv [B,h,w,2C] (v at channel offset v_off), scores scratch [B,H,W,heads] fp32
+hipError_t launch_cla(int dtype, const void* q, int ldq, const void* kv, int ldkv, int v_off, float* scores, void* out, int ldo, int B, int H,
+                      int W, int h, int w, int C, int heads, float scale, float r2, hipStream_t s);
+hipError_t launch_export_tokens(int dtype, const void* src, int ld, float* dst, long tokens, int C, hipStream_t s);
+
 // ---- NMS (k_nms.hip) ----
 struct NmsArgs {
     const float* det;   // [B, N, no]

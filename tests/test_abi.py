@@ -44,13 +44,22 @@ def _state_spec(m):
 
 
 IMPLEMENTED = {"ConvolutionBlock", "FocusBlock", "BottleneckBlock", "CSPBlock", "SPPBlock", "ChannelAttention",
-               "SpatialAttention", "CombinedAttention", "Backbone", "FeatureNeck", "DetectionHead"}
+               "SpatialAttention", "CombinedAttention", "Backbone", "FeatureNeck", "DetectionHead", "CrossLayerAttention",
+               "CrossLayerAttentionD4", "TransformerLayer", "WindowedSelfAttention"}
 
 
 @pytest.mark.parametrize("case", [c for c in BLOCK_CASES if c["kind"] in IMPLEMENTED], ids=lambda c: c["name"])
 def test_engine_param_spec_equals_module_state_dict(case):
     m = build_module(case)
     assert dict(m.expected_state()) == _state_spec(m)
+
+
+def test_enhanced_detector_param_spec_equals_state_dict():
+    m = build_detector(MODELS["skyeye_s"], enhanced=True)
+    spec = dict(m.expected_state())
+    assert spec == _state_spec(m)
+    assert spec["cross_attention_p5_p4.key_projection.weight"] == (256, 512, 1, 1)      # D4: key -> query width
+    assert spec["cross_attention_p4_p3.output_projection.weight"] == (128, 128, 1, 1)
 
 
 @pytest.mark.parametrize("model", sorted(MODELS))

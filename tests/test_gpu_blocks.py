@@ -15,7 +15,8 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 BLOCKS = np.load(os.path.join(G, "blocks.npz"))
 
 IMPLEMENTED = {"ConvolutionBlock", "FocusBlock", "BottleneckBlock", "CSPBlock", "SPPBlock", "ChannelAttention",
-               "SpatialAttention", "CombinedAttention", "Backbone", "FeatureNeck", "DetectionHead"}
+               "SpatialAttention", "CombinedAttention", "Backbone", "FeatureNeck", "DetectionHead", "CrossLayerAttention",
+               "CrossLayerAttentionD4", "TransformerLayer", "WindowedSelfAttention"}
 CASES = [c for c in BLOCK_CASES if c["kind"] in IMPLEMENTED]
 
 
@@ -34,6 +35,10 @@ def run_engine(case, precision):
             assert torch.equal(a, b)
         assert torch.equal(det, det2), "standalone decode differs from the fused head epilogue"
         outs = [det] + list(raw)
+    elif kind in ("CrossLayerAttention", "CrossLayerAttentionD4"):
+        outs = [m(ins["q"], ins["k"])]
+    elif kind == "WindowedSelfAttention":
+        outs = [m(ins["x"], ins.get("mask"))]
     else:
         outs = m(ins["x"])
         if torch.is_tensor(outs):

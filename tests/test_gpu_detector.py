@@ -16,7 +16,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 DET_FULL = np.load(os.path.join(G, "detectors_full.npz"))
 DET_SAMPLED = np.load(os.path.join(G, "detectors_sampled.npz"))
 
-CASES = [c for c in DETECTOR_CASES if not c.get("enhanced")]
+CASES = list(DETECTOR_CASES)
 _MODELS = {}
 
 
@@ -40,6 +40,12 @@ def run(case, precision, as_uint8=False):
     return det.cpu().numpy(), [r.cpu().numpy() for r in raw]
 
 
+def tol_for(case):
+    # the cross-layer attention of the Enhanced detector (column softmax over image rows, x4) amplifies fp32
+    # summation-order differences ~2.5x more than the plain graph; the oracle itself sits at 2.5e-4 from torch there
+    return 3e-4 if case.get("enhanced") else 1e-4
+
+
 def check_against_fixture(case, det, raw, tol):
     name = case["name"]
     scales = level_scales(case["hw"])
@@ -61,7 +67,7 @@ def check_against_fixture(case, det, raw, tol):
 def test_detector_fp32_matches_reference_fixture(case):
     det, raw = run(case, "fp32")
     assert det.shape[1] == sum(3 * (case["hw"][0] // s) * (case["hw"][1] // s) for s in (8, 16, 32))
-    check_against_fixture(case, det, raw, 1e-4)
+    check_against_fixture(case, det, raw, tol_for(case))
 
 
 def test_uint8_input_equals_float_input():
@@ -84,7 +90,8 @@ def test_detector_bf16_agreement(case):
     obj_err = np.abs(det[..., 4] - ref[..., 4]).max()
     print(f"{case['name']}: class agreement {agree:.4f}, max |d obj| {obj_err:.4f}")
     assert agree > 0.9
-    assert obj_err < 0.15
+    # the Enhanced detector's column softmax (x4) amplifies bf16 rounding of the projections
+    assert obj_err < (0.35 if case.get("enhanced") else 0.15)
 
 
 def test_train_mode_returns_raw_only():

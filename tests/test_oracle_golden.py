@@ -89,9 +89,11 @@ def test_detector_small_matches_reference(case):
     # relative-to-magnitude: boxes reach 4e4 (anchor*stride quirk), fp32 ulp there is 4e-3
     ref = DET_FULL[f"{case['name']}.det"]
     assert det.shape == ref.shape
-    det_close(det, ref, level_scales(case["hw"]))
+    # Enhanced detector: the cross-layer attention (column softmax, x4) amplifies summation-order differences ~2.5x
+    tol = 3e-4 if case.get("enhanced") else 1e-4
+    det_close(det, ref, level_scales(case["hw"]), tol)
     for i, r in enumerate(raw):
-        close(r, DET_FULL[f"{case['name']}.raw{i}"], rtol=5e-5)
+        close(r, DET_FULL[f"{case['name']}.raw{i}"], rtol=5e-5 * tol / 1e-4)
 
 
 @pytest.mark.parametrize("case", [c for c in BIG if c["name"] in ("s_640",)], ids=["s_640"])
