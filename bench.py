@@ -154,9 +154,9 @@ def main():
         stream = torch.cuda.current_stream(dev).cuda_stream
         prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], stream, iters=3)
         by = {}
-        for ms, fl, tag in prof:
-            e = by.setdefault(tag, [0.0, 0.0, 0])
-            e[0] += ms; e[1] += fl; e[2] += 1
+        for i, (ms, fl, tag) in enumerate(prof):
+            e = by.setdefault(tag, [0.0, 0.0, 0, 0.0])
+            e[0] += ms; e[1] += fl; e[2] += 1; e[3] += h.op_bytes(i)
         conv = {t: v for t, v in by.items() if t // 10000 == 2}      # OP_CONV
         dom_tag, dom = max(conv.items(), key=lambda kv: kv[1][0])
         variant = dom_tag % 10000
@@ -168,9 +168,20 @@ def main():
         tot_ms = sum(v[0] for v in by.values())
         peak = PEAK_TFLOPS[a.precision]
         ach = dom[1] / (dom[0] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):     # latest PMC pass (tools/pmc_traffic.sh)
+            try:
+                tv = json.load(open(f))["by_variant"].get(str(variant))
+                if tv and a.model == "skyeye_s" and B == 32 and S == 1280 and a.precision == "bf16":
+                    traffic, traffic_src = round(tv["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+            except Exception:  # noqa: BLE001
+                pass
         out["roofline"] = {
             "bound": "mfma", "kernel": kname,
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dom[3] / dom[2]),
+            "hbm_gbps_algorithmic": round(dom[3] / (dom[0] * 1e-3) / 1e9, 1),
             "launches_per_step": dom[2], "avg_launch_ms": round(dom[0] / dom[2], 4),
             "flops_per_launch": dom[1] / dom[2],
             "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "conv_ms_per_step": round(conv_ms, 3),
@@ -186,6 +197,7 @@ def main():
         # CPU baseline: the oracle (plain C + OpenMP port of the reference path) on the host cores of this box,
         # same weights, same kind of frames, bounded sample.  Checker code only -- never on the product path.
         from oracle import skyeye_oracle as O
+        O.set_threads(min(64, os.cpu_count() or 1))          # beyond ~64 threads the band-parallel C port stops scaling
         Pc = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()}
         from cases import MODELS
         nc = MODELS[a.model]["nc"]

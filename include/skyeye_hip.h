@@ -207,6 +207,9 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
  * profiling reports.  Returns SKY_ERR_INVALID past the last launch. */
 int sky_op_info(const sky_handle* h, int index, char* text, int text_len);
 
+/* Algorithmic HBM bytes of launch `index` (activation input + output + residual views, in the engine's dtype). */
+int sky_op_bytes(const sky_handle* h, int index, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,8 +31,6 @@
 #include <omp.h>
 #endif
 
-#define CB 8    /* output channels per work item */
-#define BAND 8  /* output rows per work item     */
 
 int sky_oracle_threads(void)
 {
@@ -52,51 +50,89 @@ void sky_oracle_set_threads(int n)
 #endif
 }
 
-/* y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[b,ci,oy*s+ky-p,ox*s+kx-p] */
+/* y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] * x[b,ci,oy*s+ky-p,ox*s+kx-p]
+ *
+ * Direct convolution with a register-tiled micro-kernel: the image is copied once into a zero-padded buffer (no
+ * border tests in the hot loop), each work item owns CB = 4 output channels x one output row x TW = 16 output
+ * columns held in 8 AVX2 accumulators across the whole (ci, ky, kx) loop, so the inner loop is
+ * 2 input loads (+ a de-interleave for stride 2) + 4 weight broadcasts + 8 FMAs.  Accumulation order per output:
+ * ci, then ky, then kx, ascending. */
+#include <immintrin.h>
+
+#define TW 16
+
+static inline void load_row16(const float* p, int stride, __m256* lo, __m256* hi)
+{
+    if (stride == 1) {
+        *lo = _mm256_loadu_ps(p);
+        *hi = _mm256_loadu_ps(p + 8);
+    } else { /* stride 2: take the even elements of 32 consecutive floats */
+        const __m256 a = _mm256_loadu_ps(p), b = _mm256_loadu_ps(p + 8), c = _mm256_loadu_ps(p + 16), d = _mm256_loadu_ps(p + 24);
+        const __m256 ab = _mm256_shuffle_ps(a, b, 0x88), cd = _mm256_shuffle_ps(c, d, 0x88);   /* a0 a2 b0 b2 | a4 a6 b4 b6 */
+        *lo = _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(ab), 0xD8));
+        *hi = _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(cd), 0xD8));
+    }
+}
+
 void sky_oracle_conv2d(const float* x, const float* w, const float* bias, float* y,
                        int B, int Cin, int H, int W, int Cout, int K, int stride, int pad)
 {
     const int Ho = (H + 2 * pad - K) / stride + 1;
     const int Wo = (W + 2 * pad - K) / stride + 1;
-    const int ncob = (Cout + CB - 1) / CB;
-    const int nband = (Ho + BAND - 1) / BAND;
-    const long items = (long)B * ncob * nband;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (long it = 0; it < items; ++it) {
-        const int band = (int)(it % nband);
-        const int cob = (int)((it / nband) % ncob);
-        const int b = (int)(it / ((long)nband * ncob));
-        const int co0 = cob * CB, co1 = co0 + CB < Cout ? co0 + CB : Cout;
-        const int oy0 = band * BAND, oy1 = oy0 + BAND < Ho ? oy0 + BAND : Ho;
-        for (int co = co0; co < co1; ++co)
-            for (int oy = oy0; oy < oy1; ++oy) {
-                float* yr = y + (((size_t)b * Cout + co) * Ho + oy) * Wo;
-                const float bv = bias ? bias[co] : 0.0f;
-                for (int ox = 0; ox < Wo; ++ox) yr[ox] = bv;
-            }
+    /* padded input: every tile may read up to TW*stride + K columns past its first column */
+    const int Wt = (Wo + TW - 1) / TW * TW;
+    const int Hp = (Ho - 1) * stride + K, Wp = (Wt - 1) * stride + K + 32;
+    float* xp = (float*)calloc((size_t)B * Cin * Hp * Wp, sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
         for (int ci = 0; ci < Cin; ++ci)
-            for (int ky = 0; ky < K; ++ky)
-                for (int kx = 0; kx < K; ++kx) {
-                    /* valid ox range: 0 <= ox*stride + kx - pad < W */
-                    int ox0 = 0, ox1 = Wo;
-                    while (ox0 < Wo && ox0 * stride + kx - pad < 0) ++ox0;
-                    while (ox1 > ox0 && (ox1 - 1) * stride + kx - pad >= W) --ox1;
-                    for (int oy = oy0; oy < oy1; ++oy) {
-                        const int iy = oy * stride + ky - pad;
-                        if (iy < 0 || iy >= H) continue;
-                        const float* xr = x + (((size_t)b * Cin + ci) * H + iy) * W + (kx - pad);
-                        for (int co = co0; co < co1; ++co) {
-                            const float wv = w[(((size_t)co * Cin + ci) * K + ky) * K + kx];
-                            float* yr = y + (((size_t)b * Cout + co) * Ho + oy) * Wo;
-                            if (stride == 1) {
-                                for (int ox = ox0; ox < ox1; ++ox) yr[ox] += wv * xr[ox];
-                            } else {
-                                for (int ox = ox0; ox < ox1; ++ox) yr[ox] += wv * xr[ox * stride];
-                            }
+            for (int iy = 0; iy < H; ++iy) {
+                const int py = iy + pad;
+                if (py >= Hp) continue;
+                float* dst = xp + (((size_t)b * Cin + ci) * Hp + py) * Wp + pad;
+                const float* src = x + (((size_t)b * Cin + ci) * H + iy) * W;
+                const int n = W < Wp - pad ? W : Wp - pad;
+                memcpy(dst, src, (size_t)n * sizeof(float));
+            }
+    const int ncob = (Cout + 3) / 4;
+    const long items = (long)B * ncob * Ho;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long it = 0; it < items; ++it) {
+        const int oy = (int)(it % Ho);
+        const int cob = (int)((it / Ho) % ncob);
+        const int b = (int)(it / ((long)Ho * ncob));
+        const int co0 = cob * 4;
+        const int nco = Cout - co0 < 4 ? Cout - co0 : 4;
+        for (int ox0 = 0; ox0 < Wo; ox0 += TW) {
+            __m256 acc[4][2];
+            for (int c = 0; c < 4; ++c) {
+                const float bv = (bias && c < nco) ? bias[co0 + c] : 0.0f;
+                acc[c][0] = acc[c][1] = _mm256_set1_ps(bv);
+            }
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float* xc = xp + (((size_t)b * Cin + ci) * Hp + (size_t)oy * stride) * Wp + (size_t)ox0 * stride;
+                const float* wc = w + ((size_t)co0 * Cin + ci) * K * K;
+                for (int ky = 0; ky < K; ++ky)
+                    for (int kx = 0; kx < K; ++kx) {
+                        __m256 lo, hi;
+                        load_row16(xc + (size_t)ky * Wp + kx, stride, &lo, &hi);
+                        for (int c = 0; c < nco; ++c) {
+                            const __m256 wv = _mm256_broadcast_ss(wc + (size_t)c * Cin * K * K + ky * K + kx);
+                            acc[c][0] = _mm256_fmadd_ps(wv, lo, acc[c][0]);
+                            acc[c][1] = _mm256_fmadd_ps(wv, hi, acc[c][1]);
                         }
                     }
-                }
+            }
+            const int n = Wo - ox0 < TW ? Wo - ox0 : TW;
+            for (int c = 0; c < nco; ++c) {
+                float tmp[TW];
+                _mm256_storeu_ps(tmp, acc[c][0]);
+                _mm256_storeu_ps(tmp + 8, acc[c][1]);
+                memcpy(y + (((size_t)b * Cout + co0 + c) * Ho + oy) * Wo + ox0, tmp, (size_t)n * sizeof(float));
+            }
+        }
     }
+    free(xp);
 }
 
 /* in-place eval BatchNorm (+ optional SiLU).  act: 0 identity, 1 SiLU */

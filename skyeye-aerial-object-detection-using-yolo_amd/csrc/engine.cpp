@@ -1399,6 +1399,19 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     return SKY_OK;
 }
 
+int sky_op_bytes(const sky_handle* h, int index, double* bytes)
+{
+    if (!h || !bytes || index < 0 || index >= (int)h->e.ops.size()) return SKY_ERR_INVALID;
+    const Op& op = h->e.ops[index];
+    const int es = h->e.esize();
+    auto sz = [&](const TV& t, int esz) { return (t.buf >= 0 || t.ext >= 0) && t.B ? (double)t.B * t.H * t.W * t.C * esz : 0.0; };
+    double b = sz(op.in, es) + sz(op.out, es) + sz(op.res, es) + sz(op.in2, es);
+    if (op.kind == OP_CONV && op.head) b += 2.0 * op.in.B * op.Ho * op.Wo * (double)op.cout * 4;   // raw + decoded, fp32
+    if (op.kind == OP_IMPORT) b += (double)op.out.B * op.src_c * op.src_h * op.src_w;                // uint8 frames (4x for fp32 input)
+    *bytes = b;
+    return SKY_OK;
+}
+
 int sky_plan_stats(const sky_handle* h, double* flops, double* activation_bytes, double* weight_bytes, int32_t* launches)
 {
     if (!h || !h->e.planned) return SKY_ERR_STATE;

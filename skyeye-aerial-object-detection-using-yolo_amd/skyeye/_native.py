@@ -55,7 +55,7 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info"]
+           "sky_nms_fetch", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
 _lib = None
 
@@ -96,6 +96,7 @@ def lib():
                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32),
                                       ctypes.POINTER(ctypes.c_int32)]
     L.sky_op_info.argtypes = [vp, ip, ctypes.c_char_p, ip]
+    L.sky_op_bytes.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_double)]
     L.sky_nms.argtypes = [vp, vp, ip, ip, ip, ctypes.POINTER(SkyNmsParams), vp, vp, vp]
     L.sky_nms_fetch.argtypes = [vp, vp, ip, vp, vp]
     _lib = L
@@ -210,6 +211,11 @@ class Handle:
         buf = ctypes.create_string_buffer(256)
         check(self.L.sky_op_info(self.h, i, buf, 256), self.h)
         return buf.value.decode()
+
+    def op_bytes(self, i):
+        b = ctypes.c_double()
+        check(self.L.sky_op_bytes(self.h, i, ctypes.byref(b)), self.h)
+        return b.value
 
     def stats(self):
         f, a, w, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
