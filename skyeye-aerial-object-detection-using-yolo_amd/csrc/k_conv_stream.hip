@@ -71,7 +71,11 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fr = lane & 15, fq = lane >> 4;      // MFMA operand role of this lane: pixel column fr, K group fq
+    // LOADER role: with SHUF, 4 adjacent lanes fetch the 64 contiguous bytes of one pixel (coalesced quads for the
+    // texture addresser) and ds_bpermute moves them into operand order; without it every lane loads its own operand.
+    constexpr bool SHUF = !RING && NF >= 4;
+    const int lpix = SHUF ? lane >> 2 : fr, lch = SHUF ? lane & 3 : fq;
     const int Cb = a.Cin * (int)sizeof(T);         // bytes of one filter tap per pixel
     const int cpt = Cb >> 4;                       // 16-byte chunks per tap
     const int Kb = KS * KS * Cb;                   // bytes of K per output pixel
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     auto decode_tile = [&](int tt) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            const int m = tt * TPX + i * 16 + fr;
+            const int m = tt * TPX + i * 16 + lpix;
             if (m >= a.M || tt >= t_end) { lvo[i] = 0; okm[i] = 0; continue; }
             if (KS == 1) {
                 lvo[i] = m * a.ldi * (int)sizeof(T);
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int c0 = (ss * 4 + kk) * 4;                 // first 16-byte chunk of this K-step (wave-uniform)
-            const int c = UTAP ? c0 : c0 + fq;
+            const int c = UTAP ? c0 : c0 + lch;
             int tap = 0, w = c;
             if (KS != 1) {
                 tap = a.cpt_shift >= 0 ? (c >> a.cpt_shift) : (c / cpt);
@@ -176,13 +180,26 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
             }
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
             const bool kok = KS == 1 ? (c < cpt) : (tap < KS * KS);
-            const int koff = (ky * a.W + kx) * a.ldi * (int)sizeof(T) + w * 16 + (UTAP ? fq * 16 : 0);
+            const int koff = (ky * a.W + kx) * a.ldi * (int)sizeof(T) + w * 16 + (UTAP ? lch * 16 : 0);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const bool ok = kok && ((okm[i] >> tap) & 1);
                 dst[i][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? lvo[i] + koff : -1, 0, 0);
             }
         }
+    };
+    // Loads are issued in LOADER order (4 adjacent lanes = 64 contiguous bytes of one pixel, so the texture addresser
+    // sees 16 coalesced quads per wave load instead of 64 single-lane accesses); the MFMA B operand wants lane
+    // fq*16+fr to hold pixel fr / chunk fq.  One ds_bpermute per dword moves the data (LDS crossbar, no LDS memory).
+    const int perm_addr = (fr * 4 + fq) * 4;
+    auto unshuffle = [&](u32x4_t (&buf)[MF][4]) {
+        if (!SHUF) return;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) buf[i][kk][e] = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)buf[i][kk][e]);
     };
     // NKK MFMA K-steps of one slab; `wb` = LDS offset of the slab's weights.
     // Software pipeline over G = NKK * NF/2 groups (K-step kk, fragment pair sp): the two weight fragments of group
@@ -318,6 +335,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
         if (RING) load_w(nsl);
         if (nsl == 0) decode_tile(nt);
         load_slab(nxt, nsl);
+        unshuffle(cur);
         compute(cur, RING ? (it & 1) * BUF : sl * BUF, sl == nslab - 1);
         if (sl == nslab - 1 && t < t_end) epilogue(t);
         if (RING) {
