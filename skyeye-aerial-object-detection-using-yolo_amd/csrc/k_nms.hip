@@ -8,7 +8,7 @@
 //   3. emit     candidate records in (row, class) order + 64-bit sort keys
 //               key = ~monotone(score) << 32 | candidate index  => ascending key order is "score descending,
 //               lower index first", the tie rule fixed by this build
-//   4. sort     bitonic sort of the keys, per image, padded to a power of two; chunks of 4096 keys in LDS
+//   4. sort     bitonic sort of the keys, per image, padded to a power of two; chunks of 16384 keys in LDS
 //   5. greedy   one wavefront per image walks the sorted candidates 64 at a time: each lane tests its box against
 //               the kept list (LDS), then the 64 lanes resolve among themselves in score order with ballots;
 //               stops at max_det kept or max_nms visited (metrics.py:434-435,443-444)
@@ -22,8 +22,8 @@
 namespace sky {
 
 static constexpr int ROWS = 256;        // rows per count/emit block
-static constexpr int CHUNK = 4096;      // keys per LDS sort block
-static constexpr int SORT_T = 512;      // threads per sort block
+static constexpr int CHUNK = 16384;     // keys per LDS sort block (128 KiB of the CU's 160 KiB LDS)
+static constexpr int SORT_T = 1024;     // threads per sort block
 
 __device__ __forceinline__ unsigned int score_key(float s)
 {
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a, i
     const long base = (long)blockIdx.x * CHUNK;
     if (base >= P || (!full && kstage > P)) return;
     const long len = P < CHUNK ? P : CHUNK;
-    __shared__ unsigned long long sk[CHUNK];
+    extern __shared__ unsigned long long sk[];   // CHUNK keys
     unsigned long long* g = a.keys + (long)b * a.cap + base;
     for (int i = threadIdx.x; i < len; i += SORT_T) sk[i] = g[i];
     __syncthreads();
@@ -318,11 +318,17 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
     hipLaunchKernelGGL(nms_emit_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
     hipLaunchKernelGGL(nms_pad_kernel, dim3((unsigned)((a.cap + 255) / 256), a.B), dim3(256), 0, s, a);
     const unsigned chunks = (unsigned)((a.cap + CHUNK - 1) / CHUNK);
-    hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), 0, s, a, 1, 0L);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * 8);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 1, 0L);
     for (long k = 2L * CHUNK; k <= a.cap; k <<= 1) {
         for (long j = k >> 1; j >= CHUNK; j >>= 1)
             hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)((a.cap / 2 + 255) / 256), a.B), dim3(256), 0, s, a, k, j);
-        hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), 0, s, a, 0, k);
+        hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 0, k);
     }
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64), (size_t)a.max_det * 5 * sizeof(float), s, a);
     return hipGetLastError();
