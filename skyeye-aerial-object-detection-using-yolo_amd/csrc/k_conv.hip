@@ -362,6 +362,8 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant
 {
     static const bool no_stream = getenv("SKY_NO_STREAM") != nullptr;   // A/B switch for profiling
     if (!no_stream) {
+        const hipError_t eh = launch_conv_halo(dtype, a, s, variant);
+        if (eh != hipErrorNotSupported) return eh;
         const hipError_t e = launch_conv_stream(dtype, a, s, variant);
         if (e != hipErrorNotSupported) return e;
     }

@@ -48,10 +48,14 @@ int conv_pick_bn(int cout);                      // N tile chosen for a given Co
 size_t conv_weight_rows(int cout);               // rows the packed weight / bias must have
 int conv_k_step(int dtype);                      // elements per 128-byte K-step
 // *variant (optional) receives which kernel ran: 1000 + N tile = implicit-GEMM tile kernel, 2000 + N_blk = streaming kernel
-// with resident weights, 3000 + N_blk = streaming kernel with the weight ring
+// with resident weights, 3000 + N_blk = streaming kernel with the weight ring, 4000 + N_blk = halo-tile 3x3 kernel
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
 // streaming path (k_conv_stream.hip): weights resident in LDS; hipErrorNotSupported when the shape is not covered
 hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
+// halo-tile path (k_conv_halo.hip): 3x3 stride 1 with >= 128 bytes of input channels, input tile staged once in LDS;
+// variant 4000 + N_blk; hipErrorNotSupported when the shape is not covered.  SKY_CONV_HALO=0 disables, =force ignores
+// the tile-fill heuristic.
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
