@@ -1058,7 +1058,15 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 } else {
                     a.out = tv_ptr(e, op.out, ins, n_in, outs, n_out);
                     a.ldo = op.out.ld;
-                    if (op.res.valid()) { a.res = tv_ptr(e, op.res, ins, n_in, outs, n_out); a.ldr = op.res.ld; }
+                    const double opix = (double)a.M * (op.up2 ? 4.0 : 1.0) - 1.0;
+                    const double oext = (opix * op.out.ld + op.cout) * e.esize();
+                    a.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
+                    if (op.res.valid()) {
+                        a.res = tv_ptr(e, op.res, ins, n_in, outs, n_out);
+                        a.ldr = op.res.ld;
+                        const double rext = (((double)a.M - 1.0) * op.res.ld + op.cout) * e.esize();
+                        a.res_bytes = rext < 2147483000.0 ? (unsigned)rext : 0u;
+                    }
                 }
                 SKY_HIP(launch_conv(e.dtype, a, s, &op.variant));
                 break;

@@ -25,7 +25,10 @@
 
 #include "conv_frag.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace sky {
 
@@ -36,8 +39,17 @@ static constexpr int HPL = HPIX * 32;         // bytes per plane: 11264 = 44 * 2
 static constexpr int HALO_BYTES = 4 * HPL;    // 45056
 static constexpr int HDMA = HPIX / 32;        // DMA instructions per plane
 
+// Device functions rather than inline builtins: LDS-DMA / s_waitcnt builtins reached from the __global__ template body
+// do not type-check in the host pass and hipcc then silently drops the kernel's host stub.
+__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// 16 bytes per lane: global (buffer rsrc, per-lane byte offset voff + uniform soff) -> LDS at `dst` + lane * 16
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst, int voff, int soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+
 template <typename T, int NF>
-__global__ void __launch_bounds__(HWV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_halo_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
     constexpr int WSLAB = NB * 128;               // bytes of one weight slab
@@ -64,17 +76,6 @@ __global__ void __launch_bounds__(HWV * 64) __attribute__((amdgpu_waves_per_eu(2
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)((long)a.Cout * wpitch), 0x00020000);
 
     // ---- per-lane constants ----
-    // halo DMA: this wave fills plane `wave`; lane -> pixel slot b*32 + (lane >> 1), 16-byte slot lane & 1
-    int hrel[HDMA];                               // (hy * W + hx) * pix_b + channel byte of this lane's chunk, or -1
-    int hyx[HDMA];                                // hy << 8 | hx
-#pragma unroll
-    for (int b = 0; b < HDMA; ++b) {
-        const int p = b * 32 + (lane >> 1);
-        const int hy = (p * 3641) >> 16, hx = p - hy * HPW;       // p / 18 for p < 352
-        const int kk = (lane & 1) ^ ((p >> 3) & 1);
-        hyx[b] = p < HPW * HPW ? (hy << 8 | hx) : -1;
-        hrel[b] = (hy * a.W + hx) * pix_b + (kk * 4 + wave) * 16;
-    }
     // weight DMA: instruction q of this wave fills LDS rows (wave*WDMA + q)*8 .. +7; lane -> row, swizzled chunk
     int wrel[WDMA];
 #pragma unroll
@@ -89,22 +90,25 @@ __global__ void __launch_bounds__(HWV * 64) __attribute__((amdgpu_waves_per_eu(2
     const int arow = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);               // weight fragment, K-step 0 (K-step 1: ^ 64)
     const int pb0 = fq * HPL + ((wave * 4) * HPW + fr) * 32;                 // pixel fragment 0, tap (0,0)
 
+    // halo DMA: this wave fills plane `wave`; in instruction b lane -> pixel slot p = b*32 + (lane >> 1), 16-byte slot
+    // lane & 1 (K-step (lane & 1) ^ (p >> 3 & 1) of the chunk).  Recomputed per call: once per 9 taps, and it keeps
+    // 22 VGPRs free for the fragment pipeline.
     auto issue_halo = [&](int bimg, int y0, int x0, int chunk) {
-        const int base = ((bimg * a.H + (y0 - 1)) * a.W + (x0 - 1)) * pix_b + chunk * 128;
+        const int base = ((bimg * a.H + (y0 - 1)) * a.W + (x0 - 1)) * pix_b + chunk * 128 + wave * 16;
 #pragma unroll
         for (int b = 0; b < HDMA; ++b) {
-            const int hy = hyx[b] >> 8, hx = hyx[b] & 255;
-            const bool ok = hyx[b] >= 0 && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(irsrc, (__attribute__((address_space(3))) void*)(halo + wave * HPL + b * 1024), 16,
-                                                     ok ? base + hrel[b] : -1, 0, 0, 0);
+            const int p = b * 32 + (lane >> 1);
+            const int hy = (p * 3641) >> 16, hx = p - hy * HPW;       // p / 18 for p < 352
+            const int kk = (lane & 1) ^ ((p >> 3) & 1);
+            const bool ok = p < HPW * HPW && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+            lds_dma16(irsrc, halo + wave * HPL + b * 1024, ok ? base + (hy * a.W + hx) * pix_b + kk * 64 : -1, 0);
         }
     };
     auto issue_w = [&](int tap, int chunk, int buf) {
         const int kb = tap * Cb + chunk * 128;
 #pragma unroll
         for (int q = 0; q < WDMA; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(wring + buf * WSLAB + (wave * WDMA + q) * 1024),
-                                                     16, wrel[q], kb, 0, 0);
+            lds_dma16(wrsrc, wring + buf * WSLAB + (wave * WDMA + q) * 1024, wrel[q], kb);
     };
 
     f32x4_t acc[NF][4];
@@ -113,115 +117,182 @@ __global__ void __launch_bounds__(HWV * 64) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // One tap = 2 K-steps x NF/2 groups; group (kk, sp) = two weight fragments (8 consecutive channels per lane) x the
+    // four pixel fragments of K-step kk.  Software pipeline: the weight pair of group g+2 is read from LDS before the 8
+    // MFMAs of group g issue (three pairs live), the pixel fragments of K-step 1 are requested right after the first
+    // weight pair; sched_barrier pins that order.
     auto compute_tap = [&](int tap, int buf) {
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
         const int toff = (ky * HPW + kx) * 32;
-        const char* wb = wring + buf * WSLAB;
+        const char* wb = wring + buf * WSLAB + arow;
+        int pa[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4_t pf[4];
+        for (int i = 0; i < 4; ++i) {
+            const int A = pb0 + toff + i * (HPW * 32);
+            pa[i] = A + (((A >> 8) & 1) << 4);
+        }
+        u32x4_t pf[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int A = pb0 + toff + i * (HPW * 32);
-                pf[i] = *reinterpret_cast<const u32x4_t*>(halo + A + ((((A >> 8) & 1) ^ kk) << 4));
+        for (int i = 0; i < 4; ++i) pf[0][i] = *reinterpret_cast<const u32x4_t*>(halo + pa[i]);
+        constexpr int HG = NF / 2, G = 2 * HG;
+        u32x4_t wq[3][2];
+#pragma unroll
+        for (int g = 0; g < G + 2; ++g) {
+            if (g < G) {
+                const int kk = g / HG, sp = g % HG;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    wq[g % 3][h] = *reinterpret_cast<const u32x4_t*>(wb + (2 * sp + h) * 2048 + (kk ? 64 - 2 * (arow & 64) : 0));
             }
+            if (g == 0) {
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wb + j * 2048 + (arow ^ (kk << 6)));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) S1<T>::mma(wf, pf[i], acc[j][i]);
+                for (int i = 0; i < 4; ++i) pf[1][i] = *reinterpret_cast<const u32x4_t*>(halo + (pa[i] ^ 16));
             }
+            if (g >= 2) {
+                const int gg = g - 2, kk = gg / HG, sp = gg % HG;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) S1<T>::mma(wq[gg % 3][h], pf[kk][i], acc[2 * sp + h][i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    auto epilogue = [&](int bimg, int y0, int x0) {
+    // Epilogue of one tile: bias, activation, residual, pack, 16-byte stores straight from the accumulators (a lane owns
+    // 8 consecutive channels per fragment pair).  Per image row (fragment i) the residual vectors are requested first and
+    // the activation math of the row runs under their latency; buffer descriptors give 32-bit offsets and let masked
+    // lanes (pixels past the image edge) use offset -1: loads return zeros, stores are dropped.
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
+    constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
+    auto epilogue = [&](int bimg, int y0, int x0, auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const bool has_res = a.res != nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oy = y0 + wave * 4 + i, ox = x0 + fr;
-            if (oy < a.H && ox < a.W) {
-                const long m = ((long)bimg * a.H + oy) * a.W + ox;
+            const bool ok = oy < a.H && ox < a.W;
+            const int m = (bimg * a.H + oy) * a.W + ox;
+            const int ooff = ok ? (m * a.ldo + n0 + fq * 8) * (int)sizeof(T) : -1;
+            u32x4_t rv[NF / 2][VB / 16];
+            if (has_res) {
+                const int roff = ok ? (m * a.ldr + n0 + fq * 8) * (int)sizeof(T) : -1;
 #pragma unroll
-                for (int s = 0; s < NF / 2; ++s) {
-                    const int nl = s * 32 + fq * 8;
-                    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
-                    const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
-                    float v[8];
+                for (int s = 0; s < NF / 2; ++s)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[2 * s][i][e] + b0[e];
-                        v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
-                    }
-                    if (a.act == ACT_SILU) {
+                    for (int h = 0; h < VB / 16; ++h)
+                        rv[s][h] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, s * 4 * VB + h * 16, 0);
+            }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = S1<T>::silu(v[e]);
-                    } else if (a.act == ACT_RELU) {
+            for (int s = 0; s < NF / 2; ++s) {
+                const int nl = s * 32 + fq * 8;
+                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
+                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
+                float v[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                    }
-                    if (a.res) {
-                        const char* rp = reinterpret_cast<const char*>(a.res) + (m * a.ldr + n0 + nl) * (long)sizeof(T);
-                        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(rp);
-                        if (sizeof(T) == 2) {
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * s][i][e] + b0[e];
+                    v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
+                }
+                acc[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                acc[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[2 * e] += __uint_as_float(r0[e] << 16);
-                                v[2 * e + 1] += __uint_as_float(r0[e] & 0xffff0000u);
-                            }
-                        } else {
-                            const u32x4_t r1 = *reinterpret_cast<const u32x4_t*>(rp + 16);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[e] += __uint_as_float(r0[e]);
-                                v[4 + e] += __uint_as_float(r1[e]);
-                            }
-                        }
-                    }
-                    const int n = n0 + nl;
+                for (int e = 0; e < 8; ++e) {
+                    if (ACT == ACT_SILU) v[e] = S1<T>::silu(v[e]);
+                    if (ACT == ACT_RELU) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                }
+                if (has_res) {
                     if (sizeof(T) == 2) {
-                        u32x4_t o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                            o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                            v[2 * e] += __uint_as_float(rv[s][0][e] << 16);
+                            v[2 * e + 1] += __uint_as_float(rv[s][0][e] & 0xffff0000u);
                         }
-                        *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.out) + m * a.ldo + n) = o;
                     } else {
-                        float* op = reinterpret_cast<float*>(a.out) + m * a.ldo + n;
-                        *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4_t*>(op + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += __uint_as_float(rv[s][e >> 2][e & 3]);
+                    }
+                }
+                if (sizeof(T) == 2) {
+                    u32x4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+                        o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB, 0);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4_t o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB + h * 16, 0);
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     };
-
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {    // uniform per workgroup
+    auto epilogue_act = [&](int bimg, int y0, int x0) {
+        if (a.act == ACT_SILU) epilogue(bimg, y0, x0, std::integral_constant<int, ACT_SILU>());
+        else if (a.act == ACT_RELU) epilogue(bimg, y0, x0, std::integral_constant<int, ACT_RELU>());
+        else epilogue(bimg, y0, x0, std::integral_constant<int, ACT_NONE>());
+    };
+    auto decode_tile = [&](int tile, int& bimg, int& y0, int& x0) {
         const int tx = tile % tiles_x;
         const int q = tile / tiles_x;
-        const int ty = q % tiles_y;
-        const int bimg = q / tiles_y;
-        const int y0 = ty * 16, x0 = tx * 16;
+        bimg = q / tiles_y;
+        y0 = (q - bimg * tiles_y) * 16;
+        x0 = tx * 16;
+    };
+
+    // ---- persistent tile loop (everything below is uniform per workgroup) ----
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    int bimg, y0, x0;
+    decode_tile(tile, bimg, y0, x0);
+    __syncthreads();                                   // bias staged
+    if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0);
+    if (!(a.dbg & 4)) issue_w(0, 0, 0);
+    for (;;) {
         for (int chunk = 0; chunk < nchunk; ++chunk) {
-            __syncthreads();                       // every wave is done with the halo and with both weight stages
-            issue_halo(bimg, y0, x0, chunk);
-            issue_w(0, chunk, 0);
+            if (chunk > 0) {
+                __syncthreads();                       // every wave is done with the halo and with both weight stages
+                if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, chunk);
+                if (!(a.dbg & 4)) issue_w(0, chunk, 0);
+            }
             for (int tap = 0; tap < 9; ++tap) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): this wave's DMA (slab `tap`, the halo) has landed
+                wait_vmcnt0();                          // vmcnt(0): this wave's DMA (slab `tap`, the halo) has landed
                 __syncthreads();                       // ... and everybody else's; compute(tap - 1) is over everywhere
-                if (tap < 8) issue_w(tap + 1, chunk, (tap + 1) & 1);
-                compute_tap(tap, tap & 1);
+                if (tap < 8 && !(a.dbg & 4)) issue_w(tap + 1, chunk, (tap + 1) & 1);
+                if (!(a.dbg & 1)) compute_tap(tap, tap & 1);
             }
         }
-        epilogue(bimg, y0, x0);
+        // the next tile's first halo chunk and weight slab are requested BEFORE this tile's epilogue: their latency runs
+        // under the activation math and the stores
+        const int next = tile + gridDim.x;
+        int nb = 0, ny0 = 0, nx0 = 0;
+        if (next < ntile) {
+            decode_tile(next, nb, ny0, nx0);
+            __syncthreads();
+            if (!(a.dbg & 2)) issue_halo(nb, ny0, nx0, 0);
+            if (!(a.dbg & 4)) issue_w(0, 0, 0);
+        }
+        if (!(a.dbg & 8)) epilogue_act(bimg, y0, x0);
+        if (next >= ntile) break;
+        tile = next; bimg = nb; y0 = ny0; x0 = nx0;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host
 template <typename T, int NF>
-static hipError_t halo_launch(const ConvArgs& a, hipStream_t s, int n_cu)
+static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
+    ConvArgs a = a0;
+    const char* dbg = getenv("SKY_CONV_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     constexpr int NB = NF * 16;
     const size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4;
     auto kern = conv_halo_kernel<T, NF>;
@@ -231,9 +302,15 @@ static hipError_t halo_launch(const ConvArgs& a, hipStream_t s, int n_cu)
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    if (a.dbg & 64) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), HWV * 64, lds);
+        fprintf(stderr, "conv_halo<NF=%d>: %d workgroups per CU with %zu B of LDS\n", NF, nb, lds);
+    }
     const int ntile = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
     int gx = ntile < 2 * n_cu ? ntile : 2 * n_cu;
-    hipLaunchKernelGGL(kern, dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s, a);
+    if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
+    kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
     return hipGetLastError();
 }
 
@@ -249,7 +326,8 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* va
     }
     const int esz = dtype == 0 ? 4 : 2;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
-    if (((long)a.Cin * esz) % 128 != 0 || a.Cout % 64 != 0 || a.in_bytes == 0) return hipErrorNotSupported;
+    if (((long)a.Cin * esz) % 128 != 0 || a.Cout % 64 != 0 || a.in_bytes == 0 || a.out_bytes == 0) return hipErrorNotSupported;
+    if (a.res && a.res_bytes == 0) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
     const char* mode = getenv("SKY_CONV_HALO");   // "0": never, "force": whenever the shape is covered

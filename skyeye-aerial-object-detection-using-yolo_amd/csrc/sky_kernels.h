@@ -32,6 +32,8 @@ struct ConvArgs {
     int ntiles;          // N tiles
     int cpt_shift;       // log2(16-byte chunks per tap) or -1 (streaming kernel)
     unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho) for the streaming kernel's pixel decode
+    int dbg;             // kernel experiments (SKY_CONV_DBG), 0 in production
+    unsigned out_bytes, res_bytes;   // extents of the output / residual views in bytes (0 = 2 GiB or more)
     unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)
     // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
     int head;
