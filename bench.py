@@ -161,7 +161,9 @@ def main():
         dom_tag, dom = max(conv.items(), key=lambda kv: kv[1][0])
         variant = dom_tag % 10000
         tname = "bf16" if a.precision == "bf16" else "float"
-        kname = (f"conv_stream_kernel<{tname}> weight-ring, N_blk {variant % 1000}" if variant >= 3000 else
+        kname = (f"conv_halo_small_kernel<{tname}> narrow-input halo tile, N_blk {variant % 1000}" if variant >= 5000 else
+                 f"conv_halo_kernel<{tname}> halo tile + weight ring, N_blk {variant % 1000}" if variant >= 4000 else
+                 f"conv_stream_kernel<{tname}> weight-ring, N_blk {variant % 1000}" if variant >= 3000 else
                  f"conv_stream_kernel<{tname}> resident weights, N_blk {variant % 1000}" if variant >= 2000 else
                  f"conv_igemm_kernel<{tname}> N tile {variant % 1000}")
         conv_ms = sum(v[0] for v in conv.values()); conv_fl = sum(v[1] for v in conv.values())

@@ -48,6 +48,83 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
 
+// Epilogue of one wave's 4 x 16 pixels (4 image rows oy0..oy0+3, column ox) x 16*NF channels: bias, activation,
+// residual, pack, 16-byte stores straight from the accumulators (a lane owns 8 consecutive channels per fragment pair,
+// first channel nlane + 32*s).  Per image row the residual vectors are requested first and the activation math of the
+// row runs under their latency; buffer descriptors give 32-bit offsets and let masked lanes (pixels past the image
+// edge) use offset -1: loads return zeros, stores are dropped.  Clears the accumulators.
+template <typename T, int NF, int ACT>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[NF][4], const float* lbias, __amdgpu_buffer_rsrc_t orsrc,
+                                              __amdgpu_buffer_rsrc_t rrsrc, int bimg, int oy0, int ox, int nlane)
+{
+    constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
+    const bool has_res = a.res != nullptr;
+    const int nl0 = nlane % (NF * 16);            // channel within the workgroup's N tile (bias in LDS)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oy = oy0 + i;
+        const bool ok = oy < a.H && ox < a.W;
+        const int m = (bimg * a.H + oy) * a.W + ox;
+        const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(T) : -1;
+        u32x4_t rv[NF / 2][VB / 16];
+        if (has_res) {
+            const int roff = ok ? (m * a.ldr + nlane) * (int)sizeof(T) : -1;
+#pragma unroll
+            for (int s = 0; s < NF / 2; ++s)
+#pragma unroll
+                for (int h = 0; h < VB / 16; ++h) rv[s][h] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, s * 4 * VB + h * 16, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < NF / 2; ++s) {
+            const int nl = s * 32 + nl0;
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
+            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[2 * s][i][e] + b0[e];
+                v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
+            }
+            acc[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (ACT == ACT_SILU) v[e] = S1<T>::silu(v[e]);
+                if (ACT == ACT_RELU) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+            }
+            if (has_res) {
+                if (sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(rv[s][0][e] << 16);
+                        v[2 * e + 1] += __uint_as_float(rv[s][0][e] & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += __uint_as_float(rv[s][e >> 2][e & 3]);
+                }
+            }
+            if (sizeof(T) == 2) {
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+                    o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB, 0);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB + h * 16, 0);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int NF>
 __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a)
 {
@@ -159,86 +236,13 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
         }
     };
 
-    // Epilogue of one tile: bias, activation, residual, pack, 16-byte stores straight from the accumulators (a lane owns
-    // 8 consecutive channels per fragment pair).  Per image row (fragment i) the residual vectors are requested first and
-    // the activation math of the row runs under their latency; buffer descriptors give 32-bit offsets and let masked
-    // lanes (pixels past the image edge) use offset -1: loads return zeros, stores are dropped.
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
-    constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
-    auto epilogue = [&](int bimg, int y0, int x0, auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-        const bool has_res = a.res != nullptr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int oy = y0 + wave * 4 + i, ox = x0 + fr;
-            const bool ok = oy < a.H && ox < a.W;
-            const int m = (bimg * a.H + oy) * a.W + ox;
-            const int ooff = ok ? (m * a.ldo + n0 + fq * 8) * (int)sizeof(T) : -1;
-            u32x4_t rv[NF / 2][VB / 16];
-            if (has_res) {
-                const int roff = ok ? (m * a.ldr + n0 + fq * 8) * (int)sizeof(T) : -1;
-#pragma unroll
-                for (int s = 0; s < NF / 2; ++s)
-#pragma unroll
-                    for (int h = 0; h < VB / 16; ++h)
-                        rv[s][h] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, s * 4 * VB + h * 16, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < NF / 2; ++s) {
-                const int nl = s * 32 + fq * 8;
-                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
-                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[2 * s][i][e] + b0[e];
-                    v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
-                }
-                acc[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                acc[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (ACT == ACT_SILU) v[e] = S1<T>::silu(v[e]);
-                    if (ACT == ACT_RELU) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                }
-                if (has_res) {
-                    if (sizeof(T) == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[2 * e] += __uint_as_float(rv[s][0][e] << 16);
-                            v[2 * e + 1] += __uint_as_float(rv[s][0][e] & 0xffff0000u);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += __uint_as_float(rv[s][e >> 2][e & 3]);
-                    }
-                }
-                if (sizeof(T) == 2) {
-                    u32x4_t o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                        o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB, 0);
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        u32x4_t o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
-                        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB + h * 16, 0);
-                    }
-                }
-            }
-        }
-    };
     auto epilogue_act = [&](int bimg, int y0, int x0) {
-        if (a.act == ACT_SILU) epilogue(bimg, y0, x0, std::integral_constant<int, ACT_SILU>());
-        else if (a.act == ACT_RELU) epilogue(bimg, y0, x0, std::integral_constant<int, ACT_RELU>());
-        else epilogue(bimg, y0, x0, std::integral_constant<int, ACT_NONE>());
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
     };
     auto decode_tile = [&](int tile, int& bimg, int& y0, int& x0) {
         const int tx = tile % tiles_x;
@@ -286,6 +290,139 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------ narrow inputs
+// Same halo idea for 32 or 64 bytes of input channels per pixel (the FocusBlock convolution of the stem, blocks.py:
+// 152-182; the 3x3 of the stage-1 bottlenecks): all of K = 9 taps x CB bytes fits in LDS next to TWO halo tiles, so
+//   * the weights are loaded once per persistent workgroup as [slab][row][256 B] with the streaming kernel's swizzle
+//     and row permutation; there is no weight ring and no barrier inside a tile;
+//   * the halo tile of tile t+1 is fetched by LDS-DMA into the other buffer while tile t computes: one barrier per tile;
+//   * halo layout [16-byte chunk plane c][pixel slot, 384][16 B]: a 64-byte K-step covers 4 chunks = CB/16 chunks of
+//     64/CB taps, so with CB = 32 lanes of K-groups 2, 3 read the NEXT tap's pixel -- only a different LDS address.
+//     16 consecutive pixels of a plane are 256 contiguous bytes and planes are 6144 B apart: conflict-free for any tap.
+//   * 2 to 4 workgroups per CU (40 to 96 KB of LDS) hide the per-tile latencies; the layers are HBM-bound.
+static constexpr int SPX = 384;               // pixel slots per plane (324 used): 6 DMA instructions of 64 pixels
+static constexpr int SPL = SPX * 16;          // bytes per plane = 24 * 256
+
+template <typename T, int CB, int NF>
+__global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArgs a)
+{
+    constexpr int NB = NF * 16;
+    constexpr int NPL = CB / 16;                  // planes
+    constexpr int HB = NPL * SPL;                 // one halo buffer
+    constexpr int KBYTES = 9 * CB;
+    constexpr int NSLAB = (KBYTES + 255) / 256;
+    constexpr int NKS = (KBYTES + 63) / 64;       // 64-byte K-steps
+    constexpr int WBUF = NB * 256;                // one slab of weights
+    constexpr int NPIECE = NPL * 6 / HWV;         // halo DMA instructions per wave per tile
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const wlds = smem;
+    char* const hlds = smem + NSLAB * WBUF;
+    float* const lbias = reinterpret_cast<float*>(smem + NSLAB * WBUF + 2 * HB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.y * NB;
+    const int tiles_x = (a.W + 15) >> 4, tiles_y = (a.H + 15) >> 4;
+    const int ntile = a.B * tiles_y * tiles_x;
+    const int pix_b = a.ldi * (int)sizeof(T);
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+
+    // ---- weights and bias: once per workgroup ----
+    {
+        const char* wsrc = reinterpret_cast<const char*>(a.w);
+        const long wpitch = (long)a.Kpad * (long)sizeof(T);
+        for (int idx = tid; idx < NSLAB * NB * 16; idx += HWV * 64) {
+            const int ss = idx / (NB * 16), rc = idx - ss * (NB * 16);
+            const int row = rc >> 4, c = rc & 15;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(wsrc + (long)(n0 + row) * wpitch + ss * 256 + c * 16);
+            const int swz = (row & 3) | (((row >> 3) & 3) << 2);
+            *reinterpret_cast<u32x4_t*>(wlds + ss * WBUF + row * 256 + ((c ^ swz) << 4)) = v;
+        }
+        for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
+    }
+
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
+
+    // per-lane K-step constants: LDS offset of (chunk plane, tap shift) for this lane's 16 bytes of K-step ks
+    int toff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int kb = ks * 64 + fq * 16;
+        int tap = kb / CB;
+        const int c = (kb - tap * CB) >> 4;
+        if (tap > 8) tap = 8;                       // K padding: the weights there are zero, the pixel must only be finite
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        toff[ks] = c * SPL + (ky * HPW + kx) * 16;
+    }
+    const int pb0 = ((wave * 4) * HPW + fr) * 16;
+    const int wrow0 = (fr >> 2) * 8 + (fr & 3);
+    const int wsw0 = (wrow0 & 3) | (((wrow0 >> 3) & 3) << 2);
+    const char* const wfrag = wlds + wrow0 * 256;
+
+    auto decode_tile = [&](int t, int& bimg, int& y0, int& x0) {
+        const int tx = t % tiles_x;
+        const int q = t / tiles_x;
+        bimg = q / tiles_y;
+        y0 = (q - bimg * tiles_y) * 16;
+        x0 = tx * 16;
+    };
+    auto issue_halo = [&](int t, int buf) {
+        int bimg, y0, x0;
+        decode_tile(t, bimg, y0, x0);
+        const int base = ((bimg * a.H + (y0 - 1)) * a.W + (x0 - 1)) * pix_b;
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            const int q = wave + HWV * j;           // piece: plane q / 6, 64-pixel block q % 6
+            const int c = q / 6, b = q - c * 6;
+            const int p = b * 64 + lane;
+            const int hy = (p * 3641) >> 16, hx = p - hy * HPW;
+            const bool ok = p < HPW * HPW && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+            lds_dma16(irsrc, hlds + buf * HB + c * SPL + b * 1024, ok ? base + (hy * a.W + hx) * pix_b + c * 16 : -1, 0);
+        }
+    };
+
+    f32x4_t acc[NF][4];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    issue_halo(tile, 0);
+    int it = 0;
+    for (;;) {
+        wait_vmcnt0();                 // this wave's halo pieces (and its stores of the previous tile) are done
+        __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer
+        const int next = tile + gridDim.x;
+        if (next < ntile) issue_halo(next, (it + 1) & 1);
+        const char* hb = hlds + (it & 1) * HB + pb0;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4_t pf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const u32x4_t*>(hb + toff[ks] + i * (HPW * 16));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wfrag + (ks >> 2) * WBUF + ((j >> 1) * 32 + (j & 1) * 4) * 256 +
+                                                                      ((((ks & 3) * 4 + fq) ^ wsw0) << 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S1<T>::mma(wf, pf[i], acc[j][i]);
+            }
+        }
+        int bimg, y0, x0;
+        decode_tile(tile, bimg, y0, x0);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        if (next >= ntile) break;
+        tile = next;
+        ++it;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <typename T, int NF>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
@@ -314,6 +451,32 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     return hipGetLastError();
 }
 
+template <typename T, int CB, int NF>
+static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
+{
+    constexpr int NB = NF * 16, NSLAB = (9 * CB + 255) / 256;
+    const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + NB * 4;
+    auto kern = conv_halo_small_kernel<T, CB, NF>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;
+    const int ntile = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+    const int gx = ntile < per_cu * n_cu ? ntile : per_cu * n_cu;
+    kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStream_t s, int n_cu)
+{
+    if (cb == 32) return nb == 32 ? halo_small_launch<T, 32, 2>(a, s, n_cu) : halo_small_launch<T, 32, 4>(a, s, n_cu);
+    return nb == 32 ? halo_small_launch<T, 64, 2>(a, s, n_cu) : halo_small_launch<T, 64, 4>(a, s, n_cu);
+}
+
 // returns hipErrorNotSupported when the shape is not covered / not worth it (caller falls back to the streaming kernel)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant)
 {
@@ -326,8 +489,10 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* va
     }
     const int esz = dtype == 0 ? 4 : 2;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
-    if (((long)a.Cin * esz) % 128 != 0 || a.Cout % 64 != 0 || a.in_bytes == 0 || a.out_bytes == 0) return hipErrorNotSupported;
-    if (a.res && a.res_bytes == 0) return hipErrorNotSupported;
+    if (a.in_bytes == 0 || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
+    const long cb = (long)a.Cin * esz;
+    const bool small = (cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0);
+    if (!small && (cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
     const char* mode = getenv("SKY_CONV_HALO");   // "0": never, "force": whenever the shape is covered
@@ -336,6 +501,12 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* va
         // partially filled tiles waste matrix work: keep the streaming kernel when less than 3/4 of the tile grid is image
         const long covered = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * 256;
         if ((long)a.H * a.W * 4 < covered * 3) return hipErrorNotSupported;
+    }
+    if (small) {
+        const int nb = a.Cout == 32 ? 32 : 64;
+        const hipError_t e = dtype == 0 ? halo_small_dispatch<float>((int)cb, nb, a, s, n_cu) : halo_small_dispatch<__bf16>((int)cb, nb, a, s, n_cu);
+        if (e == hipSuccess && variant) *variant = 5000 + nb;
+        return e;
     }
     const int nb = a.Cout % 128 == 0 ? 128 : 64;
     hipError_t e;

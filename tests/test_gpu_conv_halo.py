@@ -26,6 +26,13 @@ CONV_CASES = [
     (256, 256, 1, 16, 16),    # four chunks, two N tiles
     (192, 192, 1, 9, 40),     # 3 chunks, N_blk 64 x 3
     (64, 64, 5, 32, 32),      # more tiles than one round of workgroups would take on a small grid
+    # narrow inputs (32 or 64 bytes of channels per pixel): resident weights, double-buffered halo
+    (16, 32, 2, 20, 24),      # the stem's shape class: bf16 32 B / fp32 64 B per pixel
+    (32, 32, 2, 33, 17),      # bf16 64 B per pixel (fp32: the wide kernel)
+    (32, 64, 1, 16, 48),
+    (16, 64, 3, 16, 16),
+    (8, 32, 1, 16, 16),       # fp32 32 B per pixel (bf16: not covered, stays on the streaming kernel)
+    (16, 32, 7, 48, 48),      # several tiles per workgroup: both halo buffers in use
 ]
 
 
@@ -97,3 +104,14 @@ def test_halo_kernel_is_what_ran():
         os.environ.pop("SKY_CONV_HALO", None)
     tags = [t for _, _, t in prof]
     assert any(t % 10000 == 4128 for t in tags), f"halo kernel did not run: tags {tags}"
+
+
+def test_narrow_halo_kernel_is_what_ran():
+    m = load_seeded(M.ConvolutionBlock(16, 32, 3, 1), 80).set_precision("bf16")
+    x = torch.randn(2, 16, 32, 32, device="cuda")
+    m(x)
+    h = m._engine([x])
+    outs = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in h.output_shapes()]
+    prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=1)
+    tags = [t for _, _, t in prof]
+    assert any(t % 10000 == 5032 for t in tags), f"narrow halo kernel did not run: tags {tags}"
