@@ -33,7 +33,7 @@
 namespace sky {
 
 static constexpr int HWV = 4;                 // waves per workgroup
-static constexpr int HPW = 18;                // halo tile edge (16 + 2)
+
 static constexpr int HPIX = 352;              // pixel slots per plane (324 used), 11 DMA instructions of 32 pixels
 static constexpr int HPL = HPIX * 32;         // bytes per plane: 11264 = 44 * 256
 static constexpr int HALO_BYTES = 4 * HPL;    // 45056
@@ -48,22 +48,39 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
 
-// Epilogue of one wave's 4 x 16 pixels (4 image rows oy0..oy0+3, column ox) x 16*NF channels: bias, activation,
+// Pixel `idx` (0..255, row-major) of a th x tw tile: tile-local row / column; row = -1 past the end of the tile.
+// SQ: the 16 x 16 tile, known at compile time (one fragment per tile row: constants fold into the LDS offsets).
+template <bool SQ>
+__device__ __forceinline__ void tile_pixel(const ConvArgs& a, int idx, int& ty, int& tx)
+{
+    if (SQ) {
+        ty = idx >> 4;
+        tx = idx & 15;
+        return;
+    }
+    ty = (int)(((unsigned)idx * a.magic_w) >> 16);     // idx / tile_w (exact for idx < 512, tile_w <= 64)
+    tx = idx - ty * a.tile_w;
+    if (ty >= a.tile_h) ty = -1;
+}
+
+// Epilogue of one wave's 4 fragments (tile pixels idx0 + 16*i, this lane's column of each) x 16*NF channels: bias, activation,
 // residual, pack, 16-byte stores straight from the accumulators (a lane owns 8 consecutive channels per fragment pair,
 // first channel nlane + 32*s).  Per image row the residual vectors are requested first and the activation math of the
 // row runs under their latency; buffer descriptors give 32-bit offsets and let masked lanes (pixels past the image
 // edge) use offset -1: loads return zeros, stores are dropped.  Clears the accumulators.
-template <typename T, int NF, int ACT>
+template <typename T, int NF, int ACT, bool SQ>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[NF][4], const float* lbias, __amdgpu_buffer_rsrc_t orsrc,
-                                              __amdgpu_buffer_rsrc_t rrsrc, int bimg, int oy0, int ox, int nlane)
+                                              __amdgpu_buffer_rsrc_t rrsrc, int bimg, int y0, int x0, int idx0, int nlane)
 {
     constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
     const bool has_res = a.res != nullptr;
     const int nl0 = nlane % (NF * 16);            // channel within the workgroup's N tile (bias in LDS)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int oy = oy0 + i;
-        const bool ok = oy < a.H && ox < a.W;
+        int ty, tx;
+        tile_pixel<SQ>(a, idx0 + i * 16, ty, tx);
+        const int oy = y0 + ty, ox = x0 + tx;
+        const bool ok = ty >= 0 && oy < a.H && ox < a.W;
         const int m = (bimg * a.H + oy) * a.W + ox;
         const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(T) : -1;
         u32x4_t rv[NF / 2][VB / 16];
@@ -125,7 +142,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
     }
 }
 
-template <typename T, int NF>
+template <typename T, int NF, bool SQ>
 __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
@@ -141,7 +158,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     const int Cb = a.Cin * (int)sizeof(T);
     const int nchunk = Cb >> 7;
     const int n0 = blockIdx.y * NB;
-    const int tiles_x = (a.W + 15) >> 4, tiles_y = (a.H + 15) >> 4;
+    const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
+    const int tiles_x = (a.W + tile_w - 1) / tile_w, tiles_y = (a.H + tile_h - 1) / tile_h;
+    const int hpw = tile_w + 2, hpix = hpw * (tile_h + 2);
     const int ntile = a.B * tiles_y * tiles_x;
     const int pix_b = a.ldi * (int)sizeof(T);     // bytes between input pixels
     const int wpitch = a.Kpad * (int)sizeof(T);
@@ -165,7 +184,13 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     }
     // fragment reads
     const int arow = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);               // weight fragment, K-step 0 (K-step 1: ^ 64)
-    const int pb0 = fq * HPL + ((wave * 4) * HPW + fr) * 32;                 // pixel fragment 0, tap (0,0)
+    int pbi[4];                                                               // pixel fragments, tap (0,0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        tile_pixel<SQ>(a, wave * 64 + i * 16 + fr, ty, tx);
+        pbi[i] = fq * HPL + (ty < 0 ? 0 : ty * hpw + tx) * 32;               // past the tile: any valid slot (never stored)
+    }
 
     // halo DMA: this wave fills plane `wave`; in instruction b lane -> pixel slot p = b*32 + (lane >> 1), 16-byte slot
     // lane & 1 (K-step (lane & 1) ^ (p >> 3 & 1) of the chunk).  Recomputed per call: once per 9 taps, and it keeps
@@ -175,9 +200,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
 #pragma unroll
         for (int b = 0; b < HDMA; ++b) {
             const int p = b * 32 + (lane >> 1);
-            const int hy = (p * 3641) >> 16, hx = p - hy * HPW;       // p / 18 for p < 352
+            const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;       // p / hpw
             const int kk = (lane & 1) ^ ((p >> 3) & 1);
-            const bool ok = p < HPW * HPW && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+            const bool ok = p < hpix && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
             lds_dma16(irsrc, halo + wave * HPL + b * 1024, ok ? base + (hy * a.W + hx) * pix_b + kk * 64 : -1, 0);
         }
     };
@@ -200,12 +225,12 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     // weight pair; sched_barrier pins that order.
     auto compute_tap = [&](int tap, int buf) {
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        const int toff = (ky * HPW + kx) * 32;
+        const int toff = (ky * hpw + kx) * 32;
         const char* wb = wring + buf * WSLAB + arow;
         int pa[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int A = pb0 + toff + i * (HPW * 32);
+            const int A = (SQ ? pbi[0] + i * (18 * 32) : pbi[i]) + toff;
             pa[i] = A + (((A >> 8) & 1) << 4);
         }
         u32x4_t pf[2][4];
@@ -240,16 +265,16 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
     auto epilogue_act = [&](int bimg, int y0, int x0) {
-        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
-        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
-        else tile_epilogue<T, NF, ACT_NONE>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
     };
     auto decode_tile = [&](int tile, int& bimg, int& y0, int& x0) {
         const int tx = tile % tiles_x;
         const int q = tile / tiles_x;
         bimg = q / tiles_y;
-        y0 = (q - bimg * tiles_y) * 16;
-        x0 = tx * 16;
+        y0 = (q - bimg * tiles_y) * tile_h;
+        x0 = tx * tile_w;
     };
 
     // ---- persistent tile loop (everything below is uniform per workgroup) ----
@@ -303,7 +328,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
 static constexpr int SPX = 384;               // pixel slots per plane (324 used): 6 DMA instructions of 64 pixels
 static constexpr int SPL = SPX * 16;          // bytes per plane = 24 * 256
 
-template <typename T, int CB, int NF>
+template <typename T, int CB, int NF, bool SQ>
 __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
@@ -322,7 +347,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.y * NB;
-    const int tiles_x = (a.W + 15) >> 4, tiles_y = (a.H + 15) >> 4;
+    const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
+    const int tiles_x = (a.W + tile_w - 1) / tile_w, tiles_y = (a.H + tile_h - 1) / tile_h;
+    const int hpw = tile_w + 2, hpix = hpw * (tile_h + 2);
     const int ntile = a.B * tiles_y * tiles_x;
     const int pix_b = a.ldi * (int)sizeof(T);
     int tile = blockIdx.x;
@@ -356,9 +383,15 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         const int c = (kb - tap * CB) >> 4;
         if (tap > 8) tap = 8;                       // K padding: the weights there are zero, the pixel must only be finite
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        toff[ks] = c * SPL + (ky * HPW + kx) * 16;
+        toff[ks] = c * SPL + (ky * hpw + kx) * 16;
     }
-    const int pb0 = ((wave * 4) * HPW + fr) * 16;
+    int pbi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        tile_pixel<SQ>(a, wave * 64 + i * 16 + fr, ty, tx);
+        pbi[i] = (ty < 0 ? 0 : ty * hpw + tx) * 16;
+    }
     const int wrow0 = (fr >> 2) * 8 + (fr & 3);
     const int wsw0 = (wrow0 & 3) | (((wrow0 >> 3) & 3) << 2);
     const char* const wfrag = wlds + wrow0 * 256;
@@ -367,8 +400,8 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         const int tx = t % tiles_x;
         const int q = t / tiles_x;
         bimg = q / tiles_y;
-        y0 = (q - bimg * tiles_y) * 16;
-        x0 = tx * 16;
+        y0 = (q - bimg * tiles_y) * tile_h;
+        x0 = tx * tile_w;
     };
     auto issue_halo = [&](int t, int buf) {
         int bimg, y0, x0;
@@ -379,8 +412,8 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
             const int q = wave + HWV * j;           // piece: plane q / 6, 64-pixel block q % 6
             const int c = q / 6, b = q - c * 6;
             const int p = b * 64 + lane;
-            const int hy = (p * 3641) >> 16, hx = p - hy * HPW;
-            const bool ok = p < HPW * HPW && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+            const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;
+            const bool ok = p < hpix && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
             lds_dma16(irsrc, hlds + buf * HB + c * SPL + b * 1024, ok ? base + (hy * a.W + hx) * pix_b + c * 16 : -1, 0);
         }
     };
@@ -398,12 +431,12 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer
         const int next = tile + gridDim.x;
         if (next < ntile) issue_halo(next, (it + 1) & 1);
-        const char* hb = hlds + (it & 1) * HB + pb0;
+        const char* hb = hlds + (it & 1) * HB;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             u32x4_t pf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const u32x4_t*>(hb + toff[ks] + i * (HPW * 16));
+            for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const u32x4_t*>(hb + (SQ ? pbi[0] + i * (18 * 16) : pbi[i]) + toff[ks]);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wfrag + (ks >> 2) * WBUF + ((j >> 1) * 32 + (j & 1) * 4) * 256 +
@@ -414,9 +447,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         }
         int bimg, y0, x0;
         decode_tile(tile, bimg, y0, x0);
-        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
-        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
-        else tile_epilogue<T, NF, ACT_NONE>(a, acc, lbias, orsrc, rrsrc, bimg, y0 + wave * 4, x0 + fr, n0 + fq * 8);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         if (next >= ntile) break;
         tile = next;
         ++it;
@@ -424,7 +457,27 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <typename T, int NF>
+// Tile shape: th x tw <= 256 output pixels whose (th+2) x (tw+2) halo fits `slots` pixel slots, chosen to waste the
+// least matrix work on this image size (16 x 16 when the sides divide; a 40-wide map gets 6 x 40).  Widths that are
+// not multiples of 16 wrap MFMA fragments across tile rows: a few 2-way LDS bank conflicts, still far cheaper than
+// idle lanes.  Returns the covered fraction of the tile grid.
+static double pick_tile(ConvArgs& a, int slots)
+{
+    double best = -1.0;
+    for (int tw = 8; tw <= 64; ++tw) {
+        int th = 256 / tw;
+        while (th > 1 && (th + 2) * (tw + 2) > slots) --th;
+        if ((th + 2) * (tw + 2) > slots) continue;
+        const double cover = (double)a.H * a.W / ((double)((a.H + th - 1) / th) * ((a.W + tw - 1) / tw) * 256.0);
+        const double score = cover - (tw % 16 ? 0.03 : 0.0);
+        if (score > best + 1e-9) { best = score; a.tile_w = tw; a.tile_h = th; }
+    }
+    a.magic_w = 65536u / (unsigned)a.tile_w + 1u;
+    a.magic_h = 65536u / (unsigned)(a.tile_w + 2) + 1u;
+    return (double)a.H * a.W / ((double)((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w) * 256.0);
+}
+
+template <typename T, int NF, bool SQ>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     ConvArgs a = a0;
@@ -432,7 +485,7 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     a.dbg = dbg ? atoi(dbg) : 0;
     constexpr int NB = NF * 16;
     const size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4;
-    auto kern = conv_halo_kernel<T, NF>;
+    auto kern = conv_halo_kernel<T, NF, SQ>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -441,22 +494,22 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     }
     if (a.dbg & 64) {
         int nb = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), HWV * 64, lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), HWV * 64, lds) != hipSuccess) nb = -1;
         fprintf(stderr, "conv_halo<NF=%d>: %d workgroups per CU with %zu B of LDS\n", NF, nb, lds);
     }
-    const int ntile = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+    const int ntile = a.B * ((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w);
     int gx = ntile < 2 * n_cu ? ntile : 2 * n_cu;
     if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
     kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
     return hipGetLastError();
 }
 
-template <typename T, int CB, int NF>
+template <typename T, int CB, int NF, bool SQ>
 static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, NSLAB = (9 * CB + 255) / 256;
     const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + NB * 4;
-    auto kern = conv_halo_small_kernel<T, CB, NF>;
+    auto kern = conv_halo_small_kernel<T, CB, NF, SQ>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -464,7 +517,7 @@ static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
         attr_done = true;
     }
     const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;
-    const int ntile = a.B * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+    const int ntile = a.B * ((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w);
     const int gx = ntile < per_cu * n_cu ? ntile : per_cu * n_cu;
     kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
     return hipGetLastError();
@@ -473,13 +526,19 @@ static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
 template <typename T>
 static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStream_t s, int n_cu)
 {
-    if (cb == 32) return nb == 32 ? halo_small_launch<T, 32, 2>(a, s, n_cu) : halo_small_launch<T, 32, 4>(a, s, n_cu);
-    return nb == 32 ? halo_small_launch<T, 64, 2>(a, s, n_cu) : halo_small_launch<T, 64, 4>(a, s, n_cu);
+    const bool sq = a.tile_w == 16 && a.tile_h == 16;
+    if (cb == 32) {
+        if (nb == 32) return sq ? halo_small_launch<T, 32, 2, true>(a, s, n_cu) : halo_small_launch<T, 32, 2, false>(a, s, n_cu);
+        return sq ? halo_small_launch<T, 32, 4, true>(a, s, n_cu) : halo_small_launch<T, 32, 4, false>(a, s, n_cu);
+    }
+    if (nb == 32) return sq ? halo_small_launch<T, 64, 2, true>(a, s, n_cu) : halo_small_launch<T, 64, 2, false>(a, s, n_cu);
+    return sq ? halo_small_launch<T, 64, 4, true>(a, s, n_cu) : halo_small_launch<T, 64, 4, false>(a, s, n_cu);
 }
 
 // returns hipErrorNotSupported when the shape is not covered / not worth it (caller falls back to the streaming kernel)
-hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant)
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* variant)
 {
+    ConvArgs a = a0;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -497,11 +556,9 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* va
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
     const char* mode = getenv("SKY_CONV_HALO");   // "0": never, "force": whenever the shape is covered
     if (mode && mode[0] == '0') return hipErrorNotSupported;
-    if (!(mode && mode[0] == 'f')) {
-        // partially filled tiles waste matrix work: keep the streaming kernel when less than 3/4 of the tile grid is image
-        const long covered = (long)((a.H + 15) / 16) * ((a.W + 15) / 16) * 256;
-        if ((long)a.H * a.W * 4 < covered * 3) return hipErrorNotSupported;
-    }
+    const double cover = pick_tile(a, small ? SPX : HPIX);
+    // partially filled tiles waste matrix work: keep the streaming kernel when less than 3/4 of the tile grid is image
+    if (!(mode && mode[0] == 'f') && cover < 0.75) return hipErrorNotSupported;
     if (small) {
         const int nb = a.Cout == 32 ? 32 : 64;
         const hipError_t e = dtype == 0 ? halo_small_dispatch<float>((int)cb, nb, a, s, n_cu) : halo_small_dispatch<__bf16>((int)cb, nb, a, s, n_cu);
@@ -509,9 +566,15 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* va
         return e;
     }
     const int nb = a.Cout % 128 == 0 ? 128 : 64;
+    const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
-    if (dtype == 0) e = nb == 128 ? halo_launch<float, 8>(a, s, n_cu) : halo_launch<float, 4>(a, s, n_cu);
-    else e = nb == 128 ? halo_launch<__bf16, 8>(a, s, n_cu) : halo_launch<__bf16, 4>(a, s, n_cu);
+    if (dtype == 0) {
+        if (nb == 128) e = sq ? halo_launch<float, 8, true>(a, s, n_cu) : halo_launch<float, 8, false>(a, s, n_cu);
+        else e = sq ? halo_launch<float, 4, true>(a, s, n_cu) : halo_launch<float, 4, false>(a, s, n_cu);
+    } else {
+        if (nb == 128) e = sq ? halo_launch<__bf16, 8, true>(a, s, n_cu) : halo_launch<__bf16, 8, false>(a, s, n_cu);
+        else e = sq ? halo_launch<__bf16, 4, true>(a, s, n_cu) : halo_launch<__bf16, 4, false>(a, s, n_cu);
+    }
     if (e == hipSuccess && variant) *variant = 4000 + nb;
     return e;
 }

@@ -31,7 +31,8 @@ struct ConvArgs {
     int M;               // B*Ho*Wo
     int ntiles;          // N tiles
     int cpt_shift;       // log2(16-byte chunks per tap) or -1 (streaming kernel)
-    unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho) for the streaming kernel's pixel decode
+    int tile_w, tile_h;         // halo-tile kernels: output tile shape (tile_w * tile_h <= 256)
+    unsigned magic_w, magic_h;  // halo-tile kernels: 2^16 / tile_w + 1, 2^16 / (tile_w + 2) + 1 (exact division of small indices)
     int dbg;             // kernel experiments (SKY_CONV_DBG), 0 in production
     unsigned out_bytes, res_bytes;   // extents of the output / residual views in bytes (0 = 2 GiB or more)
     unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)

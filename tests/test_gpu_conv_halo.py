@@ -26,6 +26,9 @@ CONV_CASES = [
     (256, 256, 1, 16, 16),    # four chunks, two N tiles
     (192, 192, 1, 9, 40),     # 3 chunks, N_blk 64 x 3
     (64, 64, 5, 32, 32),      # more tiles than one round of workgroups would take on a small grid
+    (256, 256, 1, 40, 40),    # 6 x 40 tiles (fragments wrap tile rows), four chunks, two N tiles
+    (64, 64, 2, 20, 20),      # 12 x 20 tiles
+    (128, 128, 1, 13, 50),    # 5 x 50 tiles, ragged at the bottom
     # narrow inputs (32 or 64 bytes of channels per pixel): resident weights, double-buffered halo
     (16, 32, 2, 20, 24),      # the stem's shape class: bf16 32 B / fp32 64 B per pixel
     (32, 32, 2, 33, 17),      # bf16 64 B per pixel (fp32: the wide kernel)
@@ -33,6 +36,7 @@ CONV_CASES = [
     (16, 64, 3, 16, 16),
     (8, 32, 1, 16, 16),       # fp32 32 B per pixel (bf16: not covered, stays on the streaming kernel)
     (16, 32, 7, 48, 48),      # several tiles per workgroup: both halo buffers in use
+    (16, 32, 2, 24, 40),      # 6 x 40 tiles
 ]
 
 
