@@ -214,9 +214,57 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         }
     __syncthreads();
 
-    if (a.head) {
+    if (a.head && a.ntiles == 1) {
         // DetectionHead.forward (detector.py:79-84): channel n = anchor*no + o -> raw[b, anchor, y, x, o]
         // process_detections (detector.py:131-141): sigmoid, xy = (2s - 0.5 + grid)*stride, wh = (2s)^2 * anchor_grid
+        // All anchors sit in this N tile.  Written in OUTPUT order: for one anchor the tile's consecutive pixels are one
+        // contiguous run of BM*no floats in raw and in det, so consecutive threads store consecutive addresses; the
+        // pixel -> (x, y, image) divisions happen once per pixel, not once per element.
+        float* gx = ot + BM * OP;                                   // [BM] grid x, [BM] grid y
+        int* rowb = reinterpret_cast<int*>(gx + 2 * BM);           // [BM] raw cell base, [BM] det row base; -1 = pixel past M
+        const int HoWo = a.Ho * a.Wo;
+        if (tid < BM) {
+            const int m = m0 + tid;
+            if (m < a.M) {
+                const int x = m % a.Wo;
+                const int t = m / a.Wo;
+                const int y = t % a.Ho;
+                const int b = t / a.Ho;
+                gx[tid] = (float)x;
+                gx[BM + tid] = (float)y;
+                rowb[tid] = m + b * (a.na - 1) * HoWo;                                   // + anchor*HoWo = raw cell
+                rowb[BM + tid] = m + (int)(b * (a.det_rows - HoWo) + a.det_off);           // + anchor*HoWo = det row
+            } else {
+                rowb[tid] = -1;
+            }
+        }
+        __syncthreads();
+        const int per = BM * a.no;
+        const unsigned magic = (unsigned)(0x100000000ull / (unsigned)a.no) + 1u;    // r / no == umulhi(r, magic) for r < 2^16
+        for (int an = 0; an < a.na; ++an) {
+#pragma clang fp contract(off)
+            const float aw = a.anchor_wh[an * 2], ah = a.anchor_wh[an * 2 + 1];
+            for (int r = tid; r < per; r += NT) {
+                const int ml = (int)__umulhi((unsigned)r, magic);
+                const int o = r - ml * a.no;
+                const int cell = rowb[ml];
+                if (cell < 0) continue;
+                const int n = an * a.no + o;
+                const float v = ot[ml * OP + n] + a.bias[n];
+                a.raw[(long)(cell + an * HoWo) * a.no + o] = v;
+                const float s = 1.0f / (1.0f + expf(-v));
+                float d;
+                if (o == 0) d = (s * 2.0f - 0.5f + gx[ml]) * a.stride_px;
+                else if (o == 1) d = (s * 2.0f - 0.5f + gx[BM + ml]) * a.stride_px;
+                else if (o == 2 || o == 3) { const float t2 = s * 2.0f; d = (t2 * t2) * (o == 2 ? aw : ah); }
+                else d = s;
+                a.det[(long)(rowb[BM + ml] + an * HoWo) * a.no + o] = d;
+            }
+        }
+        return;
+    }
+    if (a.head) {
+        // several N tiles (na * no > 128): element-wise form of the same epilogue
 #pragma clang fp contract(off)
         for (int idx = tid; idx < BM * BN; idx += NT) {
             const int ml = idx / BN, nl = idx - ml * BN;
@@ -331,7 +379,8 @@ template <typename T, int WM, int WN, int MF, int NF>
 static hipError_t launch_one(const ConvArgs& a, hipStream_t s)
 {
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
-    constexpr size_t lds = (2 * (BM + BN) * 128 > BM * (BN + 4) * 4) ? 2 * (BM + BN) * 128 : BM * (BN + 4) * 4;
+    constexpr size_t epi = BM * (BN + 4) * 4 + 4 * BM * 4;   // epilogue tile + per-pixel head tables
+    constexpr size_t lds = (2 * (BM + BN) * 128 > epi) ? 2 * (BM + BN) * 128 : epi;
     static bool attr_set = false;
     auto kern = conv_igemm_kernel<T, WM, WN, MF, NF>;
     if (!attr_set) {
