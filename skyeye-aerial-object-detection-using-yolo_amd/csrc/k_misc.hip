@@ -180,42 +180,74 @@ hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, 
 }
 
 // ------------------------------------------------------------------------------------------------ max pool 5x5
+// Separable: a thread owns one (image, column, 16-byte channel vector) and walks SEG output rows downwards keeping the
+// horizontal 5-max of the last five input rows in registers: 5 loads per row instead of 25 per output.  Out-of-image
+// taps are clamped to the edge, which a max cannot see (the edge pixel is already in the window) -- the same result as
+// MaxPool2d's -inf padding, and every load is unconditional.
 template <typename T>
 __global__ void maxpool5_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int B, int H, int W, int C)
 {
     constexpr int N = Vec<T>::N;
+    constexpr int SEG = 8;
     const int cg = C / N;
-    const long total = (long)B * H * W * cg;
+    const int nseg = (H + SEG - 1) / SEG;
+    const long total = (long)B * nseg * W * cg;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
-        const long p = i / cg;
-        const int x = (int)(p % W);
-        const long t = p / W;
-        const int y = (int)(t % H);
-        const int b = (int)(t / H);
-        float m[N];
+        long t = i / cg;
+        const int x = (int)(t % W);
+        t /= W;
+        const int seg = (int)(t % nseg);
+        const int b = (int)(t / nseg);
+        const T* img = src + (long)b * H * W * lds_ + g * N;
+        int xs[5];
 #pragma unroll
-        for (int e = 0; e < N; ++e) m[e] = -INFINITY;
-        for (int dy = -2; dy <= 2; ++dy) {
-            const int yy = y + dy;
-            if ((unsigned)yy >= (unsigned)H) continue;
-            for (int dx = -2; dx <= 2; ++dx) {
-                const int xx = x + dx;
-                if ((unsigned)xx >= (unsigned)W) continue;
-                float v[N];
-                Vec<T>::load(src + (((long)b * H + yy) * W + xx) * lds_ + g * N, v);
-#pragma unroll
-                for (int e = 0; e < N; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-            }
+        for (int d = 0; d < 5; ++d) {
+            int xx = x + d - 2;
+            xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+            xs[d] = xx * lds_;
         }
-        Vec<T>::store(dst + p * ldd + g * N, m);
+        auto rowmax = [&](int yy, float* out) {
+            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+            const T* row = img + (long)yy * W * lds_;
+            float v[5][N];
+#pragma unroll
+            for (int d = 0; d < 5; ++d) Vec<T>::load(row + xs[d], v[d]);
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                float m = v[0][e];
+#pragma unroll
+                for (int d = 1; d < 5; ++d) m = v[d][e] > m ? v[d][e] : m;
+                out[e] = m;
+            }
+        };
+        const int y0 = seg * SEG, y1 = y0 + SEG < H ? y0 + SEG : H;
+        float r[5][N];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rowmax(y0 - 2 + j, r[j]);
+        for (int y = y0; y < y1; ++y) {
+            rowmax(y + 2, r[4]);
+            float m[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                float mm = r[0][e];
+#pragma unroll
+                for (int j = 1; j < 5; ++j) mm = r[j][e] > mm ? r[j][e] : mm;
+                m[e] = mm;
+            }
+            Vec<T>::store(dst + (((long)b * H + y) * W + x) * ldd + g * N, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < N; ++e) r[j][e] = r[j + 1][e];
+        }
     }
 }
 
 hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, hipStream_t s)
 {
     const int N = dtype == 0 ? 4 : 8;
-    const long total = (long)B * H * W * (C / N);
+    const long total = (long)B * ((H + 7) / 8) * W * (C / N);
     const int grid = cap_grid((total + 255) / 256);
     if (dtype == 0) hipLaunchKernelGGL(maxpool5_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, lds_, (float*)dst, ldd, B, H, W, C);
     else hipLaunchKernelGGL(maxpool5_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C);
@@ -301,26 +333,61 @@ hipError_t launch_decode(const float* raw, float* det, int B, int na, int gh, in
 template <typename T>
 __global__ void ca_reduce_kernel(const T* __restrict__ x, int ld, int HW, int C, int nchunk, float* __restrict__ part)
 {
+    // 16-byte channel vectors; the block's 256 threads are (pixel lane, channel group): each pixel lane strides the
+    // chunk's pixels, the lanes are combined through LDS in a fixed order (deterministic, no atomics).
+    constexpr int N = Vec<T>::N;
+    extern __shared__ float red[];                    // [2][npl][cpb * N]
     const int b = blockIdx.y, chunk = blockIdx.x;
     const long per = ((long)HW + nchunk - 1) / nchunk;
     const long p0 = chunk * per, p1 = (p0 + per < HW) ? p0 + per : HW;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.0f, m = -INFINITY;
-        for (long p = p0; p < p1; ++p) {
-            const float v = to_f32<T>(x[((long)b * HW + p) * ld + c]);
-            s += v;
-            m = v > m ? v : m;
+    const int CG = C / N;
+    const int cpb = CG < (int)blockDim.x ? CG : (int)blockDim.x;     // channel groups per pass
+    const int npl = blockDim.x / cpb;                               // pixel lanes
+    const int cgl = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+    float* o = part + ((long)(b * nchunk + chunk) * 2) * C;
+    for (int cg0 = 0; cg0 < CG; cg0 += cpb) {
+        const int cg = cg0 + cgl;
+        float sv[N], mv[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) { sv[e] = 0.0f; mv[e] = -INFINITY; }
+        if (pl < npl && cg < CG)
+            for (long p = p0 + pl; p < p1; p += npl) {
+                float v[N];
+                Vec<T>::load(x + ((long)b * HW + p) * ld + cg * N, v);
+#pragma unroll
+                for (int e = 0; e < N; ++e) { sv[e] += v[e]; mv[e] = v[e] > mv[e] ? v[e] : mv[e]; }
+            }
+        if (pl < npl) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                red[(pl * cpb + cgl) * N + e] = sv[e];
+                red[(npl * cpb + pl * cpb + cgl) * N + e] = mv[e];
+            }
         }
-        float* o = part + ((long)(b * nchunk + chunk) * 2) * C;
-        o[c] = s;
-        o[C + c] = m;
+        __syncthreads();
+        for (int c = threadIdx.x; c < cpb * N; c += blockDim.x) {
+            if (cg0 * N + c < C) {
+                float s2 = 0.0f, m2 = -INFINITY;
+                for (int k = 0; k < npl; ++k) {
+                    s2 += red[k * cpb * N + c];
+                    const float mk = red[(npl + k) * cpb * N + c];
+                    m2 = mk > m2 ? mk : m2;
+                }
+                o[cg0 * N + c] = s2;
+                o[C + cg0 * N + c] = m2;
+            }
+        }
+        __syncthreads();
     }
 }
 
 hipError_t launch_ca_reduce(int dtype, const void* x, int ld, int B, int HW, int C, int nchunk, float* part, hipStream_t s)
 {
-    if (dtype == 0) hipLaunchKernelGGL(ca_reduce_kernel<float>, dim3(nchunk, B), dim3(256), 0, s, (const float*)x, ld, HW, C, nchunk, part);
-    else hipLaunchKernelGGL(ca_reduce_kernel<__bf16>, dim3(nchunk, B), dim3(256), 0, s, (const __bf16*)x, ld, HW, C, nchunk, part);
+    const int n = dtype == 0 ? 4 : 8;
+    const int cg = C / n, cpb = cg < 256 ? cg : 256, npl = 256 / cpb;
+    const size_t lds = (size_t)2 * npl * cpb * n * sizeof(float);
+    if (dtype == 0) hipLaunchKernelGGL(ca_reduce_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, ld, HW, C, nchunk, part);
+    else hipLaunchKernelGGL(ca_reduce_kernel<__bf16>, dim3(nchunk, B), dim3(256), lds, s, (const __bf16*)x, ld, HW, C, nchunk, part);
     return hipGetLastError();
 }
 
@@ -379,29 +446,48 @@ hipError_t launch_ca_mlp(const float* part, int B, int HW, int C, int nchunk, in
 // SpatialAttention statistics (attention.py:91-92): mean and max over channels of x (optionally pre-scaled by the
 // channel gate, which is CombinedAttention's x1 = x * att).  One wave per pixel, lanes stride the channels.
 template <typename T>
-__global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __restrict__ att, int B, int HW, int C,
+__global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __restrict__ att, int B, int HW, int C, int lp,
                                 float* __restrict__ stats)
 {
+    // lp lanes (a power of two <= 64) share one pixel, each owning 16-byte channel vectors lane, lane + lp, ...
+    constexpr int N = Vec<T>::N;
     const int lane = threadIdx.x & 63;
+    const int sub = lane & (lp - 1);
+    const int ppw = 64 / lp;                                        // pixels per wave
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwave = ((long)gridDim.x * blockDim.x) >> 6;
     const long total = (long)B * HW;
-    for (long p = wave; p < total; p += nwave) {
-        const int b = (int)(p / HW);
+    const int CG = C / N;
+    for (long p0 = wave * ppw; p0 < total; p0 += nwave * ppw) {
+        const long p = p0 + lane / lp;
         float s = 0.0f, m = -INFINITY;
-        for (int c = lane; c < C; c += 64) {
-            float v = to_f32<T>(x[p * ld + c]);
-            if (att) v = v * att[(long)b * C + c];
-            s += v;
-            m = v > m ? v : m;
-        }
+        if (p < total) {
+            const int b = (int)((unsigned)p / (unsigned)HW);
+            const float* ab = att ? att + (long)b * C : nullptr;
+            for (int g = sub; g < CG; g += lp) {
+                float v[N];
+                Vec<T>::load(x + p * ld + g * N, v);
+                if (ab) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+                    for (int q = 0; q < N / 4; ++q) {
+                        const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(ab + g * N + q * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[q * 4 + e] = v[q * 4 + e] * a4[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    s += v[e];
+                    m = v[e] > m ? v[e] : m;
+                }
+            }
+        }
+        for (int o = lp >> 1; o > 0; o >>= 1) {
             s += __shfl_xor(s, o);
             const float mo = __shfl_xor(m, o);
             m = mo > m ? mo : m;
         }
-        if (lane == 0) {
+        if (sub == 0 && p < total) {
             stats[p * 2] = s / (float)C;
             stats[p * 2 + 1] = m;
         }
@@ -411,9 +497,12 @@ __global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __
 hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, int B, int HW, int C, float* stats, hipStream_t s)
 {
     const long total = (long)B * HW;
-    const int grid = cap_grid((total + 3) / 4);
-    if (dtype == 0) hipLaunchKernelGGL(sa_stats_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, att, B, HW, C, stats);
-    else hipLaunchKernelGGL(sa_stats_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ld, att, B, HW, C, stats);
+    const int cg = C / (dtype == 0 ? 4 : 8);
+    int lp = 1;
+    while (lp < cg && lp < 64) lp <<= 1;
+    const int grid = cap_grid((total * lp + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(sa_stats_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, att, B, HW, C, lp, stats);
+    else hipLaunchKernelGGL(sa_stats_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ld, att, B, HW, C, lp, stats);
     return hipGetLastError();
 }
 
