@@ -1401,7 +1401,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
+                 op.head ? " head" : "", op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     return SKY_OK;

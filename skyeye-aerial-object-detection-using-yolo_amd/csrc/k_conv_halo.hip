@@ -80,8 +80,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
         int ty, tx;
         tile_pixel<SQ>(a, idx0 + i * 16, ty, tx);
         const int oy = y0 + ty, ox = x0 + tx;
-        const bool ok = ty >= 0 && oy < a.H && ox < a.W;
-        const int m = (bimg * a.H + oy) * a.W + ox;
+        const bool ok = ty >= 0 && oy < a.Ho && ox < a.Wo;
+        const int m = (bimg * a.Ho + oy) * a.Wo + ox;
         const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(T) : -1;
         u32x4_t rv[NF / 2][VB / 16];
         if (has_res) {
@@ -142,7 +142,23 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
     }
 }
 
-template <typename T, int NF, bool SQ>
+// Step q of the 9 taps of one channel chunk.  Stride 1: taps in order, one halo tile.  Stride 2 (S2): the input pixel
+// of output (y, x), tap (ky, kx) is (2y + ky - 1, 2x + kx - 1): its row parity is fixed by ky (even for ky = 1, odd for
+// ky = 0 and 2), likewise its column.  So the input splits into four parity phases; each phase is staged as a
+// (th+1) x (tw+1) halo tile of "cells" (cell (cy, cx) of phase (dy, dx) = pixel (2cy + dy, 2cx + dx)) and serves the
+// 4, 2, 2 or 1 taps of that parity as ordinary unit-stride taps with cell offsets -1 (k = 0) or 0 (k = 1, 2).
+struct TapStep { int tap, dy, dx, newhalo; };
+template <bool S2>
+__device__ __forceinline__ TapStep tap_step(int q)
+{
+    if (!S2) return TapStep{q, 0, 0, q == 0};
+    // taps {0,2,6,8} odd/odd, {1,7} odd rows/even cols, {3,5} even rows/odd cols, {4} even/even
+    const int tap = (int)((0x453718620ull >> (4 * q)) & 15);
+    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+    return TapStep{tap, ky != 1, kx != 1, q == 0 || q == 4 || q == 6 || q == 8};
+}
+
+template <typename T, int NF, bool SQ, bool S2>
 __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
@@ -159,7 +175,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     const int nchunk = Cb >> 7;
     const int n0 = blockIdx.y * NB;
     const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
-    const int tiles_x = (a.W + tile_w - 1) / tile_w, tiles_y = (a.H + tile_h - 1) / tile_h;
+    const int tiles_x = (a.Wo + tile_w - 1) / tile_w, tiles_y = (a.Ho + tile_h - 1) / tile_h;
     const int hpw = tile_w + 2, hpix = hpw * (tile_h + 2);
     const int ntile = a.B * tiles_y * tiles_x;
     const int pix_b = a.ldi * (int)sizeof(T);     // bytes between input pixels
@@ -195,15 +211,18 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     // halo DMA: this wave fills plane `wave`; in instruction b lane -> pixel slot p = b*32 + (lane >> 1), 16-byte slot
     // lane & 1 (K-step (lane & 1) ^ (p >> 3 & 1) of the chunk).  Recomputed per call: once per 9 taps, and it keeps
     // 22 VGPRs free for the fragment pipeline.
-    auto issue_halo = [&](int bimg, int y0, int x0, int chunk) {
-        const int base = ((bimg * a.H + (y0 - 1)) * a.W + (x0 - 1)) * pix_b + chunk * 128 + wave * 16;
+    auto issue_halo = [&](int bimg, int y0, int x0, int chunk, int dy, int dx) {
+        // halo slot (hy, hx) = input pixel (y0 - 1 + hy, x0 - 1 + hx), or with S2 phase pixel (2(y0-1+hy)+dy, 2(x0-1+hx)+dx)
+        const int ry0 = S2 ? 2 * (y0 - 1) + dy : y0 - 1, rx0 = S2 ? 2 * (x0 - 1) + dx : x0 - 1;
+        const int base = ((bimg * a.H + ry0) * a.W + rx0) * pix_b + chunk * 128 + wave * 16;
 #pragma unroll
         for (int b = 0; b < HDMA; ++b) {
             const int p = b * 32 + (lane >> 1);
             const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;       // p / hpw
             const int kk = (lane & 1) ^ ((p >> 3) & 1);
-            const bool ok = p < hpix && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
-            lds_dma16(irsrc, halo + wave * HPL + b * 1024, ok ? base + (hy * a.W + hx) * pix_b + kk * 64 : -1, 0);
+            const int sy = S2 ? 2 * hy : hy, sx = S2 ? 2 * hx : hx;
+            const bool ok = p < hpix && (unsigned)(ry0 + sy) < (unsigned)a.H && (unsigned)(rx0 + sx) < (unsigned)a.W;
+            lds_dma16(irsrc, halo + wave * HPL + b * 1024, ok ? base + (sy * a.W + sx) * pix_b + kk * 64 : -1, 0);
         }
     };
     auto issue_w = [&](int tap, int chunk, int buf) {
@@ -225,7 +244,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     // weight pair; sched_barrier pins that order.
     auto compute_tap = [&](int tap, int buf) {
         const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-        const int toff = (ky * hpw + kx) * 32;
+        const int toff = S2 ? ((ky != 0) * hpw + (kx != 0)) * 32 : (ky * hpw + kx) * 32;
         const char* wb = wring + buf * WSLAB + arow;
         int pa[4];
 #pragma unroll
@@ -278,36 +297,43 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     };
 
     // ---- persistent tile loop (everything below is uniform per workgroup) ----
+    // A tile is the linear sequence g = chunk * 9 + q of (halo phase, tap) steps; weight slab g + 1 is requested while
+    // step g computes, a new halo tile (new chunk or, with S2, new parity phase) after a barrier at its first step.
     int tile = blockIdx.x;
     if (tile >= ntile) return;
     int bimg, y0, x0;
     decode_tile(tile, bimg, y0, x0);
+    const int G = nchunk * 9;
+    const TapStep first = tap_step<S2>(0);
     __syncthreads();                                   // bias staged
-    if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0);
-    if (!(a.dbg & 4)) issue_w(0, 0, 0);
+    if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0, first.dy, first.dx);
+    if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
     for (;;) {
-        for (int chunk = 0; chunk < nchunk; ++chunk) {
-            if (chunk > 0) {
-                __syncthreads();                       // every wave is done with the halo and with both weight stages
-                if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, chunk);
-                if (!(a.dbg & 4)) issue_w(0, chunk, 0);
+        int chunk = 0, q = 0;
+        for (int g = 0; g < G; ++g) {
+            const TapStep st = tap_step<S2>(q);
+            if (st.newhalo && g > 0) {
+                __syncthreads();                       // every wave is done with the halo tile
+                if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, chunk, st.dy, st.dx);
             }
-            for (int tap = 0; tap < 9; ++tap) {
-                wait_vmcnt0();                          // vmcnt(0): this wave's DMA (slab `tap`, the halo) has landed
-                __syncthreads();                       // ... and everybody else's; compute(tap - 1) is over everywhere
-                if (tap < 8 && !(a.dbg & 4)) issue_w(tap + 1, chunk, (tap + 1) & 1);
-                if (!(a.dbg & 1)) compute_tap(tap, tap & 1);
-            }
+            wait_vmcnt0();                              // vmcnt(0): this wave's DMA (slab g, the halo) has landed
+            __syncthreads();                           // ... and everybody else's; compute(g - 1) is over everywhere
+            int nq = q + 1, nchk = chunk;
+            if (nq == 9) { nq = 0; ++nchk; }
+            if (g + 1 < G && !(a.dbg & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
+            if (!(a.dbg & 1)) compute_tap(st.tap, g & 1);
+            q = nq;
+            chunk = nchk;
         }
-        // the next tile's first halo chunk and weight slab are requested BEFORE this tile's epilogue: their latency runs
+        // the next tile's first halo tile and weight slab are requested BEFORE this tile's epilogue: their latency runs
         // under the activation math and the stores
         const int next = tile + gridDim.x;
         int nb = 0, ny0 = 0, nx0 = 0;
         if (next < ntile) {
             decode_tile(next, nb, ny0, nx0);
             __syncthreads();
-            if (!(a.dbg & 2)) issue_halo(nb, ny0, nx0, 0);
-            if (!(a.dbg & 4)) issue_w(0, 0, 0);
+            if (!(a.dbg & 2)) issue_halo(nb, ny0, nx0, 0, first.dy, first.dx);
+            if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
         }
         if (!(a.dbg & 8)) epilogue_act(bimg, y0, x0);
         if (next >= ntile) break;
@@ -468,16 +494,16 @@ static double pick_tile(ConvArgs& a, int slots)
         int th = 256 / tw;
         while (th > 1 && (th + 2) * (tw + 2) > slots) --th;
         if ((th + 2) * (tw + 2) > slots) continue;
-        const double cover = (double)a.H * a.W / ((double)((a.H + th - 1) / th) * ((a.W + tw - 1) / tw) * 256.0);
+        const double cover = (double)a.Ho * a.Wo / ((double)((a.Ho + th - 1) / th) * ((a.Wo + tw - 1) / tw) * 256.0);
         const double score = cover - (tw % 16 ? 0.03 : 0.0);
         if (score > best + 1e-9) { best = score; a.tile_w = tw; a.tile_h = th; }
     }
     a.magic_w = 65536u / (unsigned)a.tile_w + 1u;
     a.magic_h = 65536u / (unsigned)(a.tile_w + 2) + 1u;
-    return (double)a.H * a.W / ((double)((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w) * 256.0);
+    return (double)a.Ho * a.Wo / ((double)((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w) * 256.0);
 }
 
-template <typename T, int NF, bool SQ>
+template <typename T, int NF, bool SQ, bool S2>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     ConvArgs a = a0;
@@ -485,7 +511,7 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     a.dbg = dbg ? atoi(dbg) : 0;
     constexpr int NB = NF * 16;
     const size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4;
-    auto kern = conv_halo_kernel<T, NF, SQ>;
+    auto kern = conv_halo_kernel<T, NF, SQ, S2>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -497,7 +523,7 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), HWV * 64, lds) != hipSuccess) nb = -1;
         fprintf(stderr, "conv_halo<NF=%d>: %d workgroups per CU with %zu B of LDS\n", NF, nb, lds);
     }
-    const int ntile = a.B * ((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w);
+    const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
     int gx = ntile < 2 * n_cu ? ntile : 2 * n_cu;
     if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
     kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
@@ -547,10 +573,10 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int esz = dtype == 0 ? 4 : 2;
-    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
+    if (a.ks != 3 || (a.stride != 1 && a.stride != 2) || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
     if (a.in_bytes == 0 || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
     const long cb = (long)a.Cin * esz;
-    const bool small = (cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0);
+    const bool small = a.stride == 1 && (cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0);
     if (!small && (cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
@@ -568,14 +594,22 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     const int nb = a.Cout % 128 == 0 ? 128 : 64;
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
-    if (dtype == 0) {
-        if (nb == 128) e = sq ? halo_launch<float, 8, true>(a, s, n_cu) : halo_launch<float, 8, false>(a, s, n_cu);
-        else e = sq ? halo_launch<float, 4, true>(a, s, n_cu) : halo_launch<float, 4, false>(a, s, n_cu);
+    if (a.stride == 2) {
+        if (dtype == 0) {
+            if (nb == 128) e = sq ? halo_launch<float, 8, true, true>(a, s, n_cu) : halo_launch<float, 8, false, true>(a, s, n_cu);
+            else e = sq ? halo_launch<float, 4, true, true>(a, s, n_cu) : halo_launch<float, 4, false, true>(a, s, n_cu);
+        } else {
+            if (nb == 128) e = sq ? halo_launch<__bf16, 8, true, true>(a, s, n_cu) : halo_launch<__bf16, 8, false, true>(a, s, n_cu);
+            else e = sq ? halo_launch<__bf16, 4, true, true>(a, s, n_cu) : halo_launch<__bf16, 4, false, true>(a, s, n_cu);
+        }
+    } else if (dtype == 0) {
+        if (nb == 128) e = sq ? halo_launch<float, 8, true, false>(a, s, n_cu) : halo_launch<float, 8, false, false>(a, s, n_cu);
+        else e = sq ? halo_launch<float, 4, true, false>(a, s, n_cu) : halo_launch<float, 4, false, false>(a, s, n_cu);
     } else {
-        if (nb == 128) e = sq ? halo_launch<__bf16, 8, true>(a, s, n_cu) : halo_launch<__bf16, 8, false>(a, s, n_cu);
-        else e = sq ? halo_launch<__bf16, 4, true>(a, s, n_cu) : halo_launch<__bf16, 4, false>(a, s, n_cu);
+        if (nb == 128) e = sq ? halo_launch<__bf16, 8, true, false>(a, s, n_cu) : halo_launch<__bf16, 8, false, false>(a, s, n_cu);
+        else e = sq ? halo_launch<__bf16, 4, true, false>(a, s, n_cu) : halo_launch<__bf16, 4, false, false>(a, s, n_cu);
     }
-    if (e == hipSuccess && variant) *variant = 4000 + nb;
+    if (e == hipSuccess && variant) *variant = (a.stride == 2 ? 6000 : 4000) + nb;
     return e;
 }
 

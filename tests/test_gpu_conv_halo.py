@@ -81,6 +81,38 @@ def test_halo_conv_matches_oracle(case, prec):
         assert float(np.abs(y_halo - y_stream).max()) <= 2.0 ** -7 * scale
 
 
+# stride 2: the four parity phases of the input staged one after the other (cin, cout, B, H, W of the INPUT)
+S2_CASES = [
+    (64, 128, 2, 32, 32),     # one chunk, 16 x 16 output tile
+    (128, 256, 1, 33, 41),    # odd input sizes (17 x 21 outputs), two chunks, two N tiles
+    (128, 128, 2, 40, 40),    # 20 x 20 outputs
+    (256, 64, 1, 16, 16),     # four chunks, N_blk 64
+    (64, 64, 3, 64, 64),      # several tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", S2_CASES, ids=["%d-%d_b%d_%dx%d" % c for c in S2_CASES])
+def test_halo_stride2_conv_matches_oracle(case, prec):
+    cin, cout, B, H, W = case
+    O = _oracle()
+    m = load_seeded(M.ConvolutionBlock(cin, cout, 3, 2), 81).set_precision(prec)
+    P = seeded_state_for(m, 81)
+    x = seeded_input("halo.s2.%d.%d" % (cin, H), (B, cin, H, W), 7, -2.0, 2.0)
+    ref = O.conv_block(P, "", x, 3, 2)
+    xg = torch.from_numpy(x).cuda()
+    y_halo = _run(m, xg, "force")
+    y_stream = _run(m, xg, "0")
+    assert y_halo.shape == ref.shape
+    if prec == "fp32":
+        close(y_halo, ref, rtol=2e-5)
+        close(y_halo, y_stream, rtol=2e-5)
+    else:
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(y_halo - ref).max()) <= 4e-2 * scale
+        assert float(np.abs(y_halo - y_stream).max()) <= 2.0 ** -7 * scale
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_halo_bottleneck_residual(prec):
     O = _oracle()
@@ -108,6 +140,17 @@ def test_halo_kernel_is_what_ran():
         os.environ.pop("SKY_CONV_HALO", None)
     tags = [t for _, _, t in prof]
     assert any(t % 10000 == 4128 for t in tags), f"halo kernel did not run: tags {tags}"
+
+
+def test_stride2_halo_kernel_is_what_ran():
+    m = load_seeded(M.ConvolutionBlock(64, 128, 3, 2), 82).set_precision("bf16")
+    x = torch.randn(2, 64, 64, 64, device="cuda")
+    m(x)
+    h = m._engine([x])
+    outs = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in h.output_shapes()]
+    prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=1)
+    tags = [t for _, _, t in prof]
+    assert any(t % 10000 == 6128 for t in tags), f"stride-2 halo kernel did not run: tags {tags}"
 
 
 def test_narrow_halo_kernel_is_what_ran():
