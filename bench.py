@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBPS = 8000.0                            # HBM3E spec peak (same table)
 GFLOP_PER_FRAME = {("skyeye_s", 1280): 83.0, ("skyeye_l", 1280): 459.7, ("skyeye_s", 640): 20.75,
                    ("skyeye_l", 1536): 661.9}
 
@@ -161,7 +162,8 @@ def main():
         dom_tag, dom = max(conv.items(), key=lambda kv: kv[1][0])
         variant = dom_tag % 10000
         tname = "bf16" if a.precision == "bf16" else "float"
-        kname = (f"conv_halo_small_kernel<{tname}> narrow-input halo tile, N_blk {variant % 1000}" if variant >= 5000 else
+        kname = (f"conv_halo_kernel<{tname}> stride-2 halo tile + weight ring, N_blk {variant % 1000}" if variant >= 6000 else
+                 f"conv_halo_small_kernel<{tname}> narrow-input halo tile, N_blk {variant % 1000}" if variant >= 5000 else
                  f"conv_halo_kernel<{tname}> halo tile + weight ring, N_blk {variant % 1000}" if variant >= 4000 else
                  f"conv_stream_kernel<{tname}> weight-ring, N_blk {variant % 1000}" if variant >= 3000 else
                  f"conv_stream_kernel<{tname}> resident weights, N_blk {variant % 1000}" if variant >= 2000 else
@@ -179,11 +181,16 @@ def main():
                     traffic, traffic_src = round(tv["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
             except Exception:  # noqa: BLE001
                 pass
+        hbm_gbps = dom[3] / (dom[0] * 1e-3) / 1e9                         # algorithmic in+out(+residual) bytes per launch / time
+        frac_mfma, frac_hbm = ach / peak, hbm_gbps / PEAK_HBM_GBPS
+        hbm_bound = frac_hbm > frac_mfma                                   # report the roof this kernel group is closer to
         out["roofline"] = {
-            "bound": "mfma", "kernel": kname,
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+            "achieved": round(hbm_gbps if hbm_bound else ach, 2), "peak": PEAK_HBM_GBPS if hbm_bound else peak,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(max(frac_hbm, frac_mfma), 4), "traffic": traffic,
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dom[3] / dom[2]),
-            "hbm_gbps_algorithmic": round(dom[3] / (dom[0] * 1e-3) / 1e9, 1),
+            "hbm_gbps_algorithmic": round(hbm_gbps, 1), "frac_hbm": round(frac_hbm, 4),
+            "tflops": round(ach, 2), "frac_mfma": round(frac_mfma, 4),
             "launches_per_step": dom[2], "avg_launch_ms": round(dom[0] / dom[2], 4),
             "flops_per_launch": dom[1] / dom[2],
             "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "conv_ms_per_step": round(conv_ms, 3),
