@@ -36,7 +36,8 @@ __device__ __forceinline__ int wswz(int row) { return (row & 3) | (((row >> 3) &
 
 // MF: 16-pixel fragments per wave tile, NF: 16-channel fragments (N_blk = 16*NF output channels per workgroup)
 // KT: 64-byte K-steps in the LAST slab of K (1, 2 or 4) -- a template parameter so that both loop bodies are branch-free
-template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT>
+// ONE: K fits one slab (1x1 convolutions with <= 256 bytes of input channels): only the KT real K-steps are fetched
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false>
 __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 {
     static_assert(NF % 2 == 0, "pairs of fragments form one 8-channel vector");
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in), 0, (int)a.in_bytes, 0x00020000);
     auto load_slab = [&](u32x4_t (&dst)[MF][4], int ss) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < (ONE ? KT : 4); ++kk) {
             const int c0 = (ss * 4 + kk) * 4;                 // first 16-byte chunk of this K-step (wave-uniform)
             const int c = UTAP ? c0 : c0 + lch;
             int tap = 0, w = c;
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     auto unshuffle = [&](u32x4_t (&buf)[MF][4]) {
         if (!SHUF) return;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < (ONE ? KT : 4); ++kk)
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
         }
     };
     auto compute = [&](const u32x4_t (&cur)[MF][4], int wb, bool last) {
-        if (KT == 4 || !last) compute_n(cur, wb, std::integral_constant<int, 4>());
+        if (KT == 4 || (!ONE && !last)) compute_n(cur, wb, std::integral_constant<int, 4>());
         else compute_n(cur, wb, std::integral_constant<int, KT>());
     };
     auto epilogue = [&](int tt) {
@@ -368,7 +369,7 @@ static StreamPlan stream_plan(int dtype, const ConvArgs& a)
     return p;
 }
 
-template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT>
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false>
 static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, TPX = MF * 16;
@@ -381,7 +382,7 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     const size_t nslab = (Kb + SLAB - 1) / SLAB;
     const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + NB * 4;
     static size_t attr_lds = 0;
-    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT>;
+    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT, ONE>;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -402,6 +403,13 @@ static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs
         return hipErrorNotSupported;
     }
     if (p.ring) return KT == 4 ? stream_launch<T, KS, 2, 8, true, true, 4>(a, s, n_cu) : hipErrorNotSupported;
+    if (KS == 1 && KT < 4 && (size_t)a.Cin * sizeof(T) <= 256) {   // one slab of K: fetch only its real K-steps
+        switch (p.nf) {
+            case 8: return stream_launch<T, 1, 2, 8, false, true, KT, true>(a, s, n_cu);
+            case 4: return stream_launch<T, 1, 2, 4, false, true, KT, true>(a, s, n_cu);
+            default: return stream_launch<T, 1, 4, 2, false, true, KT, true>(a, s, n_cu);
+        }
+    }
     switch (p.nf) {
         case 8:
             if (KT == 4) return stream_launch<T, KS, 2, 8, false, true, 4>(a, s, n_cu);
