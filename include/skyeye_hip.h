@@ -185,6 +185,12 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
             int32_t* counts, void* stream);
 int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream);
 
+/* box_iou (metrics.py:17-44), the pairwise IoU of the evaluation accounting (validate.py:71-108 process_batch):
+ * out[n, m] fp32 on the device.  box1_is_4xn = 1 reads box1 as [4, n] -- the indexing the file actually performs
+ *  --, 0 as [n, 4]; box2 is [m, 4], corners (x1, y1, x2, y2).  Asynchronous on `stream`. */
+int sky_box_iou(sky_handle* h, const float* box1, int n, int box1_is_4xn, const float* box2, int m, float* out,
+                void* stream);
+
 /* Engine statistics for the bench harness: algorithmic FLOPs (2*MAC over conv/linear) and activation bytes
  * of the planned graph, number of launches per forward. */
 int sky_plan_stats(const sky_handle* h, double* flops, double* activation_bytes, double* weight_bytes,

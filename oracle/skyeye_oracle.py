@@ -367,3 +367,45 @@ def non_max_suppression(prediction, conf_threshold=0.25, iou_threshold=0.45, cla
         c = cols.value
         out.append(buf.reshape(-1)[: n * c].reshape(n, c).copy() if n else np.zeros((0, 6), np.float32))
     return out
+
+
+# --------------------------------------------------------------------------- evaluation accounting
+def box_iou(box1, box2, literal=True):
+    """box_iou (metrics.py:17-44) in fp32 numpy, the file's operation order.  literal: box1 is [4, N] (what the file
+    indexes); otherwise [N, 4].  box2 is [M, 4].  -> [N, M]."""
+    b1 = np.asarray(box1, np.float32)
+    if not literal:
+        b1 = b1.T
+    b2 = np.asarray(box2, np.float32).T
+    e = np.float32(1e-7)
+    inter = np.clip(np.minimum(b1[2][:, None], b2[2]) - np.maximum(b1[0][:, None], b2[0]), 0, None) * \
+        np.clip(np.minimum(b1[3][:, None], b2[3]) - np.maximum(b1[1][:, None], b2[1]), 0, None)
+    w1, h1 = b1[2] - b1[0], b1[3] - b1[1] + e
+    w2, h2 = b2[2] - b2[0], b2[3] - b2[1] + e
+    union = (w1[:, None] * h1[:, None]) + (w2 * h2) - inter + e
+    return (inter / union).astype(np.float32)
+
+
+def process_batch(detections, labels, iouv):
+    """process_batch (validate.py:71-108) as the YOLOv5 rule it imitates (the file's body cannot run): python loops,
+    written independently of the product's vectorised form.  -> bool [n, len(iouv)]."""
+    det, lab = np.asarray(detections, np.float32), np.asarray(labels, np.float32)
+    n, m = det.shape[0], lab.shape[0]
+    correct = np.zeros((n, len(iouv)), dtype=bool)
+    if n == 0 or m == 0:
+        return correct
+    iou = box_iou(lab[:, 1:5], det[:, :4], literal=False)          # [m, n]
+    for t, thr in enumerate(iouv):
+        pairs = [(float(iou[l, d]), l, d) for l in range(m) for d in range(n) if iou[l, d] >= thr and lab[l, 0] == det[d, 5]]
+        # best IoU first; then keep the first pair of every detection (in detection order), then of every label
+        pairs.sort(key=lambda x: -x[0])
+        by_det = {}
+        for p in pairs:
+            by_det.setdefault(p[2], p)
+        kept = [by_det[d] for d in sorted(by_det)]
+        by_lab = {}
+        for p in kept:
+            by_lab.setdefault(p[1], p)
+        for p in by_lab.values():
+            correct[p[2], t] = True
+    return correct

@@ -1467,6 +1467,16 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
     });
 }
 
+int sky_box_iou(sky_handle* h, const float* box1, int n, int box1_is_4xn, const float* box2, int m, float* out, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (n < 0 || m < 0) throw Error(SKY_ERR_SHAPE, "sky_box_iou: negative box count");
+        if ((n && !box1) || (m && !box2) || ((long)n * m && !out)) throw Error(SKY_ERR_INVALID, "sky_box_iou: null argument");
+        SKY_HIP(launch_box_iou(box1, n, box1_is_4xn ? 1 : 0, box2, m, out, (hipStream_t)stream));
+    });
+}
+
 int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream)
 {
     if (!h) return SKY_ERR_INVALID;

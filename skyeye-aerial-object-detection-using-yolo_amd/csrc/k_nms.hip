@@ -334,4 +334,40 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ box_iou
+// Pairwise IoU of evaluation accounting (reference metrics.py:17-44, used by validate.py:process_batch :71-108):
+// inter = clamp(min(x2) - max(x1), 0) * clamp(min(y2) - max(y1), 0); heights carry + 1e-7, the union one more 1e-7;
+// the same operation order as the tensor expression ((w1*h1 + w2*h2) - inter) + 1e-7, no FMA contraction (this file).
+// box1 is [4, n] (the file's literal indexing, box1_4xn = 1) or [n, 4]; box2 is [m, 4]; out is [n, m].
+__global__ void box_iou_kernel(const float* __restrict__ b1, int n, int b1_4xn, const float* __restrict__ b2, int m, float* __restrict__ out)
+{
+    const long total = (long)n * m;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / m), j = (int)(idx - (long)i * m);
+        float ax1, ay1, ax2, ay2;
+        if (b1_4xn) { ax1 = b1[i]; ay1 = b1[n + i]; ax2 = b1[2 * n + i]; ay2 = b1[3 * n + i]; }
+        else { ax1 = b1[4 * i]; ay1 = b1[4 * i + 1]; ax2 = b1[4 * i + 2]; ay2 = b1[4 * i + 3]; }
+        const float bx1 = b2[4 * j], by1 = b2[4 * j + 1], bx2 = b2[4 * j + 2], by2 = b2[4 * j + 3];
+        float iw = fminf(ax2, bx2) - fmaxf(ax1, bx1);
+        float ih = fminf(ay2, by2) - fmaxf(ay1, by1);
+        iw = iw > 0.0f ? iw : 0.0f;
+        ih = ih > 0.0f ? ih : 0.0f;
+        const float inter = iw * ih;
+        const float w1 = ax2 - ax1, h1 = ay2 - ay1 + 1e-7f;
+        const float w2 = bx2 - bx1, h2 = by2 - by1 + 1e-7f;
+        const float uni = (w1 * h1) + (w2 * h2) - inter + 1e-7f;
+        out[idx] = inter / uni;
+    }
+}
+
+hipError_t launch_box_iou(const float* box1, int n, int box1_4xn, const float* box2, int m, float* out, hipStream_t s)
+{
+    const long total = (long)n * m;
+    if (total == 0) return hipSuccess;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(box_iou_kernel, dim3((unsigned)grid), dim3(256), 0, s, box1, n, box1_4xn, box2, m, out);
+    return hipGetLastError();
+}
+
 }  // namespace sky

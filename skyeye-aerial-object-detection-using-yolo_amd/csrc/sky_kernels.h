@@ -124,5 +124,7 @@ struct NmsArgs {
 };
 size_t nms_workspace_bytes(int B, int N, int nc, int multi_label, long* cap_out);
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
+// pairwise IoU [n, m] of the evaluation accounting (metrics.py:17-44); box1 [4, n] (box1_4xn) or [n, 4], box2 [m, 4]
+hipError_t launch_box_iou(const float* box1, int n, int box1_4xn, const float* box2, int m, float* out, hipStream_t s);
 
 }  // namespace sky

@@ -66,3 +66,125 @@ def non_max_suppression(prediction, conf_threshold=0.25, iou_threshold=0.45, cla
     for b, n in enumerate(host):
         res.append(out[b, :n, :cols] if n else torch.zeros((0, 6), device=prediction.device))
     return res
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Evaluation accounting: box_iou, process_batch, compute_ap, ap_per_class.
+# The pairwise IoU runs on the MI355X (sky_box_iou); the AP bookkeeping is host-side numpy in the reference
+# (metrics.py:124-225) and stays host-side here.
+def box_iou(box1, box2, layout="literal"):
+    """Pairwise IoU -> [N, M] (reference metrics.py:17-44), computed on the device.
+
+    ``layout='literal'``: box1 is indexed the way the file indexes it, ``box1[0..3]`` = x1, y1, x2, y2 *rows*, i.e. a
+    [4, N] tensor, although its docstring says (N, 4).  ``layout='rows'``: box1 is [N, 4].
+    box2 is [M, 4] in both.  Heights carry the file's + 1e-7, the union one more."""
+    if not (box1.is_cuda and box2.is_cuda):
+        raise N.SkyEyeNativeError("box_iou: boxes must be on the HIP device (no CPU path)")
+    a = box1.float().contiguous()
+    b = box2.float().contiguous()
+    four_by_n = layout == "literal"
+    if a.dim() != 2 or b.dim() != 2 or b.shape[1] != 4 or a.shape[0 if four_by_n else 1] != 4:
+        raise ValueError(f"box_iou: box1 {tuple(a.shape)} / box2 {tuple(b.shape)} do not fit layout '{layout}'")
+    n, m = a.shape[1 if four_by_n else 0], b.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=a.device)
+    h = _handle(a.device.index or 0)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    N.check(h.L.sky_box_iou(h.h, a.data_ptr(), n, int(four_by_n), b.data_ptr(), m, out.data_ptr(), ctypes.c_void_p(stream)), h.h)
+    return out
+
+
+def process_batch(detections, labels, iouv):
+    """Correct-prediction matrix [n, len(iouv)] (reference validate.py:71-108).
+
+    detections [n, 6] = (x1, y1, x2, y2, conf, cls), labels [m, 5] = (cls, x1, y1, x2, y2), iouv = IoU thresholds.
+    The reference body cannot run (box_iou is handed [m, 4] where it indexes [4, m]; ``torch.unique`` has no
+    ``return_index``): this is the YOLOv5 rule it imitates -- per threshold, candidate (label, detection) pairs of the
+    same class with IoU >= threshold, best IoU first, each detection and each label used once.  IoU on the device, the
+    (small) matching on the host.  PARITY UNPINNED against the reference (no runnable form); pinned against oracle/."""
+    import numpy as np
+    iouv_h = iouv.detach().cpu().numpy() if torch.is_tensor(iouv) else np.asarray(iouv)
+    n, m = detections.shape[0], labels.shape[0]
+    correct = np.zeros((n, iouv_h.shape[0]), dtype=bool)
+    if n and m:
+        iou = box_iou(labels[:, 1:5], detections[:, :4], layout="rows").cpu().numpy()            # [m, n]
+        same = labels[:, 0:1].cpu().numpy() == detections[:, 5].cpu().numpy()[None, :]
+        for i, thr in enumerate(iouv_h):
+            li, di = np.nonzero((iou >= thr) & same)
+            if li.size:
+                matches = np.stack([li, di, iou[li, di]], 1)
+                if li.size > 1:
+                    matches = matches[np.argsort(-matches[:, 2], kind="stable")]
+                    matches = matches[np.unique(matches[:, 1], return_index=True)[1]]
+                    matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
+                correct[matches[:, 1].astype(np.int64), i] = True
+    dev = iouv.device if torch.is_tensor(iouv) else detections.device
+    return torch.from_numpy(correct).to(dev)
+
+
+def compute_ap(recall, precision):
+    """(AP, precision envelope, recall) of one precision/recall curve (reference metrics.py:124-148): sentinels
+    (0, 0) and (1, 0), running maximum from the right, area where recall changes."""
+    import numpy as np
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([0.0], precision, [0.0]))
+    mpre = np.maximum.accumulate(mpre[::-1])[::-1]
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    ap = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    return ap, mpre, mrec
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls, plot=False, save_dir=None, names=()):
+    """Per-class precision, recall, AP [classes, len(iouv)], F1 and the class list (reference metrics.py:151-225).
+    Detections are ranked by confidence; P/R curves are sampled on 1000 confidence points from the IoU-0.5 column; the
+    returned P, R, F1 are taken where the class-mean F1 peaks.  ``plot`` is accepted and ignored (plots are out of scope)."""
+    import numpy as np
+    tp, conf, pred_cls, target_cls = np.asarray(tp), np.asarray(conf), np.asarray(pred_cls), np.asarray(target_cls)
+    order = np.argsort(-conf)
+    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
+    unique_classes = np.unique(target_cls)
+    nc = unique_classes.shape[0]
+    px = np.linspace(0, 1, 1000)
+    ap = np.zeros((nc, tp.shape[1]))
+    precision = np.zeros((nc, 1000))
+    recall = np.zeros((nc, 1000))
+    for ci, c in enumerate(unique_classes):
+        sel = pred_cls == c
+        n_gt = (target_cls == c).sum()
+        if sel.sum() == 0 or n_gt == 0:
+            continue
+        fpc = (1 - tp[sel]).cumsum(0)
+        tpc = tp[sel].cumsum(0)
+        recall_curve = tpc / (n_gt + 1e-16)
+        recall[ci] = np.interp(-px, -conf[sel], recall_curve[:, 0])
+        precision_curve = tpc / (tpc + fpc)
+        precision[ci] = np.interp(-px, -conf[sel], precision_curve[:, 0])
+        for j in range(tp.shape[1]):
+            ap[ci, j], _, _ = compute_ap(recall_curve[:, j], precision_curve[:, j])
+    f1 = 2 * precision * recall / (precision + recall + 1e-16)
+    i = f1.mean(0).argmax()
+    return precision[:, i], recall[:, i], ap, f1[:, i], unique_classes
+
+
+def mean_average_precision(predictions, labels, iouv=None):
+    """validate.py:262-318 for one list of images: predictions = per-image [n, 6] (x1, y1, x2, y2, conf, cls) device
+    tensors, labels = per-image [m, 5] (cls, x1, y1, x2, y2).  -> dict(mp, mr, map50, map, ap [classes, 10], classes)."""
+    import numpy as np
+    dev = predictions[0].device if len(predictions) else torch.device("cuda")
+    if iouv is None:
+        iouv = torch.linspace(0.5, 0.95, 10, device=dev)                          # validate.py:203
+    stats = []
+    for pred, lab in zip(predictions, labels):
+        tcls = lab[:, 0].cpu().numpy() if lab.shape[0] else np.zeros((0,))
+        if pred.shape[0] == 0:
+            if lab.shape[0]:
+                stats.append((np.zeros((0, iouv.shape[0]), dtype=bool), np.zeros((0,)), np.zeros((0,)), tcls))
+            continue
+        correct = process_batch(pred, lab, iouv) if lab.shape[0] else torch.zeros((pred.shape[0], iouv.shape[0]), dtype=torch.bool)
+        stats.append((correct.cpu().numpy(), pred[:, 4].cpu().numpy(), pred[:, 5].cpu().numpy(), tcls))
+    if not stats:
+        return dict(mp=0.0, mr=0.0, map50=0.0, map=0.0, ap=np.zeros((0, iouv.shape[0])), classes=np.zeros((0,)))
+    tp, conf, pcls, tcls = [np.concatenate(x, 0) for x in zip(*stats)]             # validate.py:305
+    if not tp.shape[0] or not tp.any():
+        return dict(mp=0.0, mr=0.0, map50=0.0, map=0.0, ap=np.zeros((0, iouv.shape[0])), classes=np.unique(tcls))
+    p, r, ap, f1, classes = ap_per_class(tp, conf, pcls, tcls)
+    return dict(mp=float(p.mean()), mr=float(r.mean()), map50=float(ap[:, 0].mean()), map=float(ap.mean()), ap=ap, classes=classes)

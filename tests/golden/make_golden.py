@@ -282,8 +282,54 @@ def gen_nms():
     np.savez_compressed(os.path.join(HERE, "nms.npz"), **out)
 
 
+def eval_inputs():
+    """Seeded inputs of the evaluation-accounting fixtures."""
+    r = np.random.default_rng(20240611)
+
+    def boxes(n, degenerate=0):
+        xy = r.uniform(0, 600, (n, 2)).astype(np.float32)
+        wh = r.uniform(2, 200, (n, 2)).astype(np.float32)
+        b = np.concatenate([xy, xy + wh], 1)
+        b[:degenerate, 2:] = b[:degenerate, :2]            # zero-area boxes
+        return b
+
+    a, b = boxes(37, 2), boxes(53, 1)
+    b[5] = a[7]                                            # an exact duplicate: IoU ~ 1
+    curves = []
+    for n in (1, 17, 400):
+        rec = np.sort(r.uniform(0, 1, n)).astype(np.float64)
+        prec = r.uniform(0, 1, n).astype(np.float64)
+        curves.append((rec, prec))
+    n, m, nc = 600, 240, 10
+    conf = r.uniform(0, 1, n)
+    tp = r.uniform(0, 1, (n, 10)) < (0.2 + 0.6 * conf[:, None])        # better-scored detections are right more often
+    tp = np.logical_and.accumulate(tp[:, ::-1], axis=1)[:, ::-1] | tp   # keep it a plausible monotone-ish matrix
+    pred_cls = r.integers(0, nc - 1, n).astype(np.float64)             # class nc-1 is never predicted
+    target_cls = r.integers(1, nc, m).astype(np.float64)               # class 0 has no labels
+    return a, b, curves, (tp, conf, pred_cls, target_cls)
+
+
+def gen_eval():
+    """box_iou metrics.py:17-44 (LITERAL: box1 is indexed as [4, N]), compute_ap :124-148, ap_per_class :151-225."""
+    metrics = load_reference_metrics()
+    a, b, curves, (tp, conf, pred_cls, target_cls) = eval_inputs()
+    out = {"iou.a": a, "iou.b": b}
+    out["iou.out"] = metrics.box_iou(torch.from_numpy(a.T.copy()), torch.from_numpy(b)).numpy()        # [37, 53]
+    for k, (rec, prec) in enumerate(curves):
+        ap, mpre, mrec = metrics.compute_ap(rec, prec)
+        out[f"ap{k}.recall"], out[f"ap{k}.precision"] = rec, prec
+        out[f"ap{k}.ap"], out[f"ap{k}.mpre"], out[f"ap{k}.mrec"] = np.float64(ap), mpre, mrec
+    p, r_, ap, f1, cls = metrics.ap_per_class(tp, conf, pred_cls, target_cls)
+    out.update({"apc.tp": tp, "apc.conf": conf, "apc.pred_cls": pred_cls, "apc.target_cls": target_cls,
+                "apc.p": p, "apc.r": r_, "apc.ap": ap, "apc.f1": f1, "apc.classes": cls})
+    np.savez_compressed(os.path.join(HERE, "eval.npz"), **out)
+    print(f"  eval: iou {out['iou.out'].shape} max {out['iou.out'].max():.6f}; ap_per_class ap {ap.shape} mean {ap.mean():.4f}")
+
+
 def main(argv):
-    what = set(argv) or {"blocks", "detectors", "nms"}
+    what = set(argv) or {"blocks", "detectors", "nms", "eval"}
+    if "eval" in what:
+        gen_eval()
     if "blocks" in what:
         gen_blocks()
     if "detectors" in what:
