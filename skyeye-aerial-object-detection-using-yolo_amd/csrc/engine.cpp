@@ -89,6 +89,9 @@ struct Op {
     int Ho = 0, Wo = 0;
     double flops = 0;
     int variant = 0;       // which conv kernel ran last (launch_conv)
+    int fuse_next = 0;     // the next op is a 1x1 convolution of (a channel slice of) this op's output: candidate for the
+                           // producer's epilogue (back-to-back GEMM from the registers that hold the packed output)
+    int fused_prev = 0;    // set on that next op; skipped at run time when the producer's kernel took it
     // attention
     int heads = 0, ntok = 0, nW = 0, mask_ext = -1, v_off = 0, force_nhwc = 0;
     float scale = 1.0f, r2 = 1.0f;
@@ -230,6 +233,24 @@ struct Ctx {
     void push(Op op)
     {
         if (!emit) return;
+        // opt-in (SKY_FUSE=1): measured neutral on MI355X -- the producer's epilogue is VALU-bound, the second GEMM and
+        // its epilogue cost what the separate 1x1 launch costs
+        const bool no_fuse = getenv("SKY_FUSE") == nullptr || getenv("SKY_NO_FUSE") != nullptr;
+        if (!no_fuse && !e.ops.empty() && op.kind == OP_CONV) {
+            Op& a = e.ops.back();
+            const long koff = op.in.off - a.out.off;
+            if (a.kind == OP_CONV && !a.head && !a.up2 && !op.head && !op.up2 && !op.res.valid() && op.ks == 1 && op.stride == 1 &&
+                a.out.buf >= 0 && op.in.buf == a.out.buf && op.in.ld == a.out.ld && op.in.B == a.out.B && op.in.H == a.out.H &&
+                op.in.W == a.out.W && koff >= 0 && koff + op.cin <= a.cout && koff % 32 == 0 && (op.cin == 32 || op.cin == 64) &&
+                (op.cout == 32 || op.cout == 64) && (a.cout == 64 || a.cout == 128) && op.out.buf >= 0 && op.out.buf != a.in.buf &&
+                op.out.buf != a.out.buf && op.out.buf != a.res.buf && !a.fused_prev) {
+                a.fuse_next = 1;
+                op.fused_prev = 1;
+                const int i = (int)e.ops.size();
+                Buffer& b = e.bufs[op.out.buf];          // written while the producer runs: alive one op earlier
+                b.first = std::min(b.first, i - 1);
+            }
+        }
         touch(op.in.buf); touch(op.out.buf); touch(op.res.buf); touch(op.in2.buf);
         touch(op.s0); touch(op.s1); touch(op.s2);
         e.flops += op.flops;
@@ -1018,7 +1039,17 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     const sky_config& cf = e.cfg;
     int op_index = 0;
     if (marks) SKY_HIP(hipEventRecord(marks[0], s));
-    for (Op& op : e.ops) {
+    bool took_next = false;     // the previous op's kernel also computed this (fused_prev) op
+    for (size_t oi = 0; oi < e.ops.size(); ++oi) {
+        Op& op = e.ops[oi];
+        if (op.fused_prev && took_next) {
+            took_next = false;
+            op.variant = 9000;
+            ++op_index;
+            if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
+            continue;
+        }
+        took_next = false;
         switch (op.kind) {
             case OP_IMPORT: {
                 const sky_buffer& src = ins[op.in.ext];
@@ -1068,7 +1099,19 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         a.res_bytes = rext < 2147483000.0 ? (unsigned)rext : 0u;
                     }
                 }
-                SKY_HIP(launch_conv(e.dtype, a, s, &op.variant));
+                if (op.fuse_next && oi + 1 < e.ops.size()) {
+                    const Op& f = e.ops[oi + 1];
+                    const DevConv& d2 = e.convs[f.wid];
+                    a.f2_w = d2.w; a.f2_bias = d2.bias; a.f2_Kpad = d2.Kpad;
+                    a.f2_out = tv_ptr(e, f.out, ins, n_in, outs, n_out);
+                    a.f2_cin = f.cin; a.f2_cout = f.cout; a.f2_ldo = f.out.ld; a.f2_act = f.act;
+                    a.f2_koff = (int)(f.in.off - op.out.off);
+                    const double fext = (((double)a.M - 1.0) * f.out.ld + f.cout) * e.esize();
+                    a.f2_out_bytes = fext < 2147483000.0 ? (unsigned)fext : 0u;
+                }
+                int fused = 0;
+                SKY_HIP(launch_conv(e.dtype, a, s, &op.variant, &fused));
+                took_next = fused != 0;
                 break;
             }
             case OP_MAXPOOL5:
@@ -1401,7 +1444,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     return SKY_OK;

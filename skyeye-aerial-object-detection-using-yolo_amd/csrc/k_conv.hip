@@ -407,13 +407,14 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
     }
 }
 
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant)
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
+    if (fused) *fused = 0;
     static const bool no_stream = getenv("SKY_NO_STREAM") != nullptr;   // A/B switch for profiling
     if (!no_stream) {
-        const hipError_t eh = launch_conv_halo(dtype, a, s, variant);
+        const hipError_t eh = launch_conv_halo(dtype, a, s, variant, fused);
         if (eh != hipErrorNotSupported) return eh;
-        const hipError_t e = launch_conv_stream(dtype, a, s, variant);
+        const hipError_t e = launch_conv_stream(dtype, a, s, variant, fused);
         if (e != hipErrorNotSupported) return e;
     }
     if (variant) *variant = 1000 + conv_pick_bn(a.Cout);

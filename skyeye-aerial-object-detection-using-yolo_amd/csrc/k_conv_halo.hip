@@ -42,6 +42,15 @@ static constexpr int HDMA = HPIX / 32;        // DMA instructions per plane
 // Device functions rather than inline builtins: LDS-DMA / s_waitcnt builtins reached from the __global__ template body
 // do not type-check in the host pass and hipcc then silently drops the kernel's host stub.
 __device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// experiment (SKY_CONV_DBG & 256): shader-clock stamps of one wave's second tile, kept in LDS, dumped at kernel end
+__device__ __forceinline__ void dbg_stamp(const ConvArgs& a, unsigned long long* st, int nth_tile, int slot)
+{
+    if ((a.dbg & 256) && nth_tile == 1 && threadIdx.x == 0) st[slot] = __builtin_amdgcn_s_memtime();
+}
+// wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue order: the N
+// youngest -- the epilogue's stores -- may stay in flight while everything older -- the LDS-DMA -- has landed)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
 // 16 bytes per lane: global (buffer rsrc, per-lane byte offset voff + uniform soff) -> LDS at `dst` + lane * 16
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst, int voff, int soff)
 {
@@ -68,9 +77,11 @@ __device__ __forceinline__ void tile_pixel(const ConvArgs& a, int idx, int& ty, 
 // first channel nlane + 32*s).  Per image row the residual vectors are requested first and the activation math of the
 // row runs under their latency; buffer descriptors give 32-bit offsets and let masked lanes (pixels past the image
 // edge) use offset -1: loads return zeros, stores are dropped.  Clears the accumulators.
-template <typename T, int NF, int ACT, bool SQ>
+// FC > 0: the packed vectors of channels [0, FC) are also kept in `bop` (the B operands of a fused 1x1, conv_frag.h).
+template <typename T, int NF, int ACT, bool SQ, int FC = 0>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[NF][4], const float* lbias, __amdgpu_buffer_rsrc_t orsrc,
-                                              __amdgpu_buffer_rsrc_t rrsrc, int bimg, int y0, int x0, int idx0, int nlane)
+                                              __amdgpu_buffer_rsrc_t rrsrc, int bimg, int y0, int x0, int idx0, int nlane,
+                                              u32x4_t (*bop)[FC / 32 ? FC / 32 : 1][FuseGeom<T>::H] = nullptr)
 {
     constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
     const bool has_res = a.res != nullptr;
@@ -129,6 +140,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB, 0);
+                if (FC > 0 && s < FC / 32) bop[i][s][0] = o;
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -136,6 +148,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
                     __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB + h * 16, 0);
+                    if (FC > 0 && s < FC / 32) bop[i][s][h] = o;
                 }
             }
         }
@@ -158,7 +171,7 @@ __device__ __forceinline__ TapStep tap_step(int q)
     return TapStep{tap, ky != 1, kx != 1, q == 0 || q == 4 || q == 6 || q == 8};
 }
 
-template <typename T, int NF, bool SQ, bool S2>
+template <typename T, int NF, bool SQ, bool S2, int FC = 0>
 __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
@@ -168,6 +181,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     char* const halo = smem;
     char* const wring = smem + HALO_BYTES;
     float* const lbias = reinterpret_cast<float*>(smem + HALO_BYTES + 2 * WSLAB);
+    char* const w2lds = smem + HALO_BYTES + 2 * WSLAB + NB * 4;                   // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
+    float* const b2lds = reinterpret_cast<float*>(w2lds + FC * FC * (int)sizeof(T));
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(b2lds + (FC ? FC : 0));   // 64 x 8 B, experiments only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -182,6 +198,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     const int wpitch = a.Kpad * (int)sizeof(T);
 
     for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
+    if (FC > 0) fuse_stage<T, FC ? FC : 32>(a.f2_w, a.f2_Kpad, a.f2_bias, w2lds, b2lds, tid, HWV * 64);
 
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc =
@@ -284,6 +301,28 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
     auto epilogue_act = [&](int bimg, int y0, int x0) {
+        if (FC > 0) {
+            // this convolution's epilogue keeps the packed first FC channels, the fused 1x1 runs from them, second epilogue
+            constexpr int C2 = FC ? FC : 32;
+            u32x4_t bop[4][C2 / 32][FuseGeom<T>::H];
+            if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, C2>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, bop);
+            else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, C2>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, bop);
+            else tile_epilogue<T, NF, ACT_NONE, SQ, C2>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, bop);
+            f32x4_t acc2[C2 / 16][4];
+#pragma unroll
+            for (int j = 0; j < C2 / 16; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc2[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            fuse_gemm<T, C2, 4>(bop, w2lds, acc2, fr, fq);
+            ConvArgs a2 = a;
+            a2.res = nullptr;
+            a2.ldo = a.f2_ldo;
+            const __amdgpu_buffer_rsrc_t o2 = __builtin_amdgcn_make_buffer_rsrc(a.f2_out, 0, (int)a.f2_out_bytes, 0x00020000);
+            if (a.f2_act == ACT_SILU) tile_epilogue<T, C2 / 16, ACT_SILU, SQ>(a2, acc2, b2lds, o2, o2, bimg, y0, x0, wave * 64 + fr, fq * 8);
+            else if (a.f2_act == ACT_RELU) tile_epilogue<T, C2 / 16, ACT_RELU, SQ>(a2, acc2, b2lds, o2, o2, bimg, y0, x0, wave * 64 + fr, fq * 8);
+            else tile_epilogue<T, C2 / 16, ACT_NONE, SQ>(a2, acc2, b2lds, o2, o2, bimg, y0, x0, wave * 64 + fr, fq * 8);
+            return;
+        }
         if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
@@ -308,20 +347,31 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     __syncthreads();                                   // bias staged
     if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0, first.dy, first.dx);
     if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
+    // store instructions one epilogue issues per wave (all unconditional; masked lanes only drop their data)
+    constexpr int NST = 4 * (NF / 2) * FuseGeom<T>::H + (FC ? 4 * (FC / 32) * FuseGeom<T>::H : 0);
+    static_assert(NST < 64, "vmcnt is a 6-bit counter");
+    bool after_epilogue = false;
+    int nth = 0;
     for (;;) {
         int chunk = 0, q = 0;
+        dbg_stamp(a, stamps, nth, 0);
         for (int g = 0; g < G; ++g) {
             const TapStep st = tap_step<S2>(q);
             if (st.newhalo && g > 0) {
                 __syncthreads();                       // every wave is done with the halo tile
                 if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, chunk, st.dy, st.dx);
             }
-            wait_vmcnt0();                              // vmcnt(0): this wave's DMA (slab g, the halo) has landed
+            // this wave's DMA (slab g, the halo) has landed.  Right after an epilogue its stores are the youngest
+            // operations: they may stay in flight, their completion latency would otherwise stall every tile
+            if (g == 0 && after_epilogue) wait_vmcnt<NST>();
+            else wait_vmcnt0();
             __syncthreads();                           // ... and everybody else's; compute(g - 1) is over everywhere
             int nq = q + 1, nchk = chunk;
             if (nq == 9) { nq = 0; ++nchk; }
+            dbg_stamp(a, stamps, nth, 1 + 2 * g);
             if (g + 1 < G && !(a.dbg & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
             if (!(a.dbg & 1)) compute_tap(st.tap, g & 1);
+            dbg_stamp(a, stamps, nth, 2 + 2 * g);
             q = nq;
             chunk = nchk;
         }
@@ -332,12 +382,25 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
         if (next < ntile) {
             decode_tile(next, nb, ny0, nx0);
             __syncthreads();
+            dbg_stamp(a, stamps, nth, 40);
             if (!(a.dbg & 2)) issue_halo(nb, ny0, nx0, 0, first.dy, first.dx);
             if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
         }
+        dbg_stamp(a, stamps, nth, 41);
         if (!(a.dbg & 8)) epilogue_act(bimg, y0, x0);
+        dbg_stamp(a, stamps, nth, 42);
+        if ((a.dbg & 256) && nth == 1) {
+            wait_vmcnt0();
+            dbg_stamp(a, stamps, nth, 43);
+        }
+        ++nth;
+        after_epilogue = !(a.dbg & 8);
         if (next >= ntile) break;
         tile = next; bimg = nb; y0 = ny0; x0 = nx0;
+    }
+    if ((a.dbg & 256) && a.raw && nth >= 2 && threadIdx.x == 0 && blockIdx.y == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.raw) + (size_t)blockIdx.x * 64;
+        for (int k = 0; k < 44; ++k) dst[k] = stamps[k];
     }
 }
 
@@ -452,8 +515,11 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
 
     issue_halo(tile, 0);
     int it = 0;
+    constexpr int NST = 4 * (NF / 2) * FuseGeom<T>::H;      // store instructions of one epilogue, all unconditional
     for (;;) {
-        wait_vmcnt0();                 // this wave's halo pieces (and its stores of the previous tile) are done
+        // this wave's halo pieces have landed; the previous tile's stores (younger than them) may stay in flight
+        if (it > 0) wait_vmcnt<NST>();
+        else wait_vmcnt0();
         __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer
         const int next = tile + gridDim.x;
         if (next < ntile) issue_halo(next, (it + 1) & 1);
@@ -503,15 +569,15 @@ static double pick_tile(ConvArgs& a, int slots)
     return (double)a.Ho * a.Wo / ((double)((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w) * 256.0);
 }
 
-template <typename T, int NF, bool SQ, bool S2>
+template <typename T, int NF, bool SQ, bool S2, int FC = 0>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     ConvArgs a = a0;
     const char* dbg = getenv("SKY_CONV_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
     constexpr int NB = NF * 16;
-    const size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4;
-    auto kern = conv_halo_kernel<T, NF, SQ, S2>;
+    const size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0) + ((a.dbg & 256) ? 512 : 0);
+    auto kern = conv_halo_kernel<T, NF, SQ, S2, FC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -526,7 +592,31 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
     int gx = ntile < 2 * n_cu ? ntile : 2 * n_cu;
     if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
+    static unsigned long long* stamps = nullptr;
+    if (a.dbg & 256) {
+        if (!stamps && hipMalloc(&stamps, 1024 * 64 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        if (hipMemsetAsync(stamps, 0, 1024 * 64 * 8, s) != hipSuccess) return hipErrorUnknown;
+        a.raw = reinterpret_cast<float*>(stamps);
+    }
     kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
+    if (a.dbg & 256) {   // experiment: mean timeline of every workgroup's second tile (shader clocks since its start)
+        static int once = 0;
+        if (once++ == 2 && hipStreamSynchronize(s) == hipSuccess) {
+            static unsigned long long h[1024 * 64];
+            if (hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                double sum[44] = {0};
+                int cnt = 0;
+                for (int w = 0; w < gx; ++w) {
+                    if (!h[w * 64] || !h[w * 64 + 42]) continue;
+                    ++cnt;
+                    for (int k = 0; k < 44; ++k) sum[k] += h[w * 64 + k] ? (double)(h[w * 64 + k] - h[w * 64]) : 0.0;
+                }
+                fprintf(stderr, "halo timeline over %d workgroups (NF=%d S2=%d FC=%d), mean shader clocks since tile start:\n", cnt, NF, (int)S2, FC);
+                for (int k = 0; k < 44; ++k)
+                    if (sum[k] > 0) fprintf(stderr, "  [%2d] %9.0f\n", k, sum[k] / (cnt ? cnt : 1));
+            }
+        }
+    }
     return hipGetLastError();
 }
 
@@ -562,7 +652,7 @@ static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStre
 }
 
 // returns hipErrorNotSupported when the shape is not covered / not worth it (caller falls back to the streaming kernel)
-hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* variant)
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* variant, int* fused)
 {
     ConvArgs a = a0;
     static int n_cu = 0;
@@ -602,6 +692,11 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
             if (nb == 128) e = sq ? halo_launch<__bf16, 8, true, true>(a, s, n_cu) : halo_launch<__bf16, 8, false, true>(a, s, n_cu);
             else e = sq ? halo_launch<__bf16, 4, true, true>(a, s, n_cu) : halo_launch<__bf16, 4, false, true>(a, s, n_cu);
         }
+    } else if (a.f2_w && nb == 64 && a.Cout == 64 && a.f2_cin == 64 && a.f2_cout == 64 && a.f2_koff == 0 && a.f2_out_bytes) {
+        // the 1x1 convolution that follows (the next bottleneck's cv1) runs in this kernel's epilogue
+        if (dtype == 0) e = sq ? halo_launch<float, 4, true, false, 64>(a, s, n_cu) : halo_launch<float, 4, false, false, 64>(a, s, n_cu);
+        else e = sq ? halo_launch<__bf16, 4, true, false, 64>(a, s, n_cu) : halo_launch<__bf16, 4, false, false, 64>(a, s, n_cu);
+        if (e == hipSuccess && fused) *fused = 1;
     } else if (dtype == 0) {
         if (nb == 128) e = sq ? halo_launch<float, 8, true, false>(a, s, n_cu) : halo_launch<float, 8, false, false>(a, s, n_cu);
         else e = sq ? halo_launch<float, 4, true, false>(a, s, n_cu) : halo_launch<float, 4, false, false>(a, s, n_cu);

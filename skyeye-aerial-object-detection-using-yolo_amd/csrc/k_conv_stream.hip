@@ -37,7 +37,9 @@ __device__ __forceinline__ int wswz(int row) { return (row & 3) | (((row >> 3) &
 // MF: 16-pixel fragments per wave tile, NF: 16-channel fragments (N_blk = 16*NF output channels per workgroup)
 // KT: 64-byte K-steps in the LAST slab of K (1, 2 or 4) -- a template parameter so that both loop bodies are branch-free
 // ONE: K fits one slab (1x1 convolutions with <= 256 bytes of input channels): only the KT real K-steps are fetched
-template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false>
+// FC > 0: a following FC -> FC 1x1 convolution of this convolution's first FC output channels runs in the epilogue
+// (ConvArgs::f2_*, conv_frag.h): the packed output vectors are its MFMA B operands
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false, int FC = 0>
 __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 {
     static_assert(NF % 2 == 0, "pairs of fragments form one 8-channel vector");
@@ -61,6 +63,8 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     const char* __restrict__ wsrc = reinterpret_cast<const char*>(a.w);
     const long wpitch = (long)a.Kpad * (long)sizeof(T);
     float* lbias = reinterpret_cast<float*>(smem + (RING ? 2 : nslab) * BUF);
+    char* const w2lds = reinterpret_cast<char*>(lbias + NB);
+    float* const b2lds = reinterpret_cast<float*>(w2lds + FC * FC * (int)sizeof(T));
 
     // ---- weight staging ----
     constexpr int WCH = (NB * 16 + SW * 64 - 1) / (SW * 64);    // 16-byte chunks per thread per slab
@@ -84,6 +88,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
         }
     };
     for (int i = tid; i < NB; i += SW * 64) lbias[i] = a.bias[n0 + i];
+    if (FC > 0) fuse_stage<T, FC ? FC : 32>(a.f2_w, a.f2_Kpad, a.f2_bias, w2lds, b2lds, tid, SW * 64);
 
     // ---- tile schedule ----
     const int ntiles = (a.M + TPX - 1) / TPX;
@@ -209,9 +214,17 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
         else compute_n(cur, wb, std::integral_constant<int, KT>());
     };
     auto epilogue = [&](int tt) {
+        constexpr int C2 = FC ? FC : 32;
+        u32x4_t bop[MF][C2 / 32][FuseGeom<T>::H];
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int m = tt * TPX + i * 16 + fr;
+            if (FC > 0) {
+#pragma unroll
+                for (int s2 = 0; s2 < C2 / 32; ++s2)
+#pragma unroll
+                    for (int h = 0; h < FuseGeom<T>::H; ++h) bop[i][s2][h] = u32x4_t{0u, 0u, 0u, 0u};
+            }
             if (m < a.M) {
                 long p0 = m;
                 int rep = 1;
@@ -272,16 +285,68 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                                 o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
                             }
                             *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.out) + p * a.ldo + n) = o;
+                            if (FC > 0 && s < FC / 32) bop[i][s][0] = o;
                         } else {
                             float* op = reinterpret_cast<float*>(a.out) + p * a.ldo + n;
                             *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
                             *reinterpret_cast<f32x4_t*>(op + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+                            if (FC > 0 && s < FC / 32) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    bop[i][s][0][e] = __float_as_uint(v[e]);
+                                    bop[i][s][FuseGeom<T>::H - 1][e] = __float_as_uint(v[4 + e]);
+                                }
+                            }
                         }
                     }
                 }
             }
 #pragma unroll
             for (int j = 0; j < NF; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if (FC > 0) {       // the fused 1x1: out2 = act2(W2 * packed[:, 0:FC] + b2)
+            f32x4_t acc2[C2 / 16][MF];
+#pragma unroll
+            for (int j = 0; j < C2 / 16; ++j)
+#pragma unroll
+                for (int i = 0; i < MF; ++i) acc2[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            fuse_gemm<T, C2, MF>(bop, w2lds, acc2, fr, fq);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int m = tt * TPX + i * 16 + fr;
+                if (m < a.M) {
+#pragma unroll
+                    for (int s = 0; s < C2 / 32; ++s) {
+                        const int nl = s * 32 + fq * 8;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc2[2 * s][i][e] + b2lds[nl + e];
+                            v[4 + e] = acc2[2 * s + 1][i][e] + b2lds[nl + 4 + e];
+                        }
+                        if (a.f2_act == ACT_SILU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = S1<T>::silu(v[e]);
+                        } else if (a.f2_act == ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                        }
+                        if (sizeof(T) == 2) {
+                            u32x4_t o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+                                o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                            }
+                            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.f2_out) + (long)m * a.f2_ldo + nl) = o;
+                        } else {
+                            float* op = reinterpret_cast<float*>(a.f2_out) + (long)m * a.f2_ldo + nl;
+                            *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4_t*>(op + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+                        }
+                    }
+                }
+            }
         }
     };
 
@@ -369,7 +434,7 @@ static StreamPlan stream_plan(int dtype, const ConvArgs& a)
     return p;
 }
 
-template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false>
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false, int FC = 0>
 static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, TPX = MF * 16;
@@ -380,9 +445,9 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
         if ((1 << sh) == cpt) a.cpt_shift = sh;
     const size_t Kb = (size_t)KS * KS * a.Cin * sizeof(T);
     const size_t nslab = (Kb + SLAB - 1) / SLAB;
-    const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + NB * 4;
+    const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
     static size_t attr_lds = 0;
-    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT, ONE>;
+    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT, ONE, FC>;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -395,9 +460,34 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     return hipGetLastError();
 }
 
-template <typename T, int KS, int KT>
-static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs& a, hipStream_t s, int n_cu)
+// the fused forms: resident weights, one N tile covering all of Cout (64 -> fused 32, 128 -> fused 64)
+template <typename T, int KT>
+static hipError_t stream_dispatch_fused(const StreamPlan& p, const ConvArgs& a, hipStream_t s, int n_cu)
 {
+    const bool one = KT < 4 && (size_t)a.Cin * sizeof(T) <= 256;
+    if (p.nf == 4) {
+        if (one) return KT < 4 ? stream_launch<T, 1, 2, 4, false, true, (KT < 4 ? KT : 1), true, 32>(a, s, n_cu) : hipErrorNotSupported;
+        return stream_launch<T, 1, 2, 4, false, true, KT, false, 32>(a, s, n_cu);
+    }
+    if (one) return KT < 4 ? stream_launch<T, 1, 2, 8, false, true, (KT < 4 ? KT : 1), true, 64>(a, s, n_cu) : hipErrorNotSupported;
+    return KT == 4 ? stream_launch<T, 1, 2, 8, false, true, 4, false, 64>(a, s, n_cu) : hipErrorNotSupported;
+}
+
+template <typename T, int KS, int KT>
+static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs& a, hipStream_t s, int n_cu, int* fused = nullptr)
+{
+    if (KS == 1 && utap && !p.ring && a.f2_w && a.f2_koff == 0 && a.f2_cin == a.f2_cout && p.nf * 16 == a.Cout &&
+        ((p.nf == 4 && a.f2_cin == 32) || (p.nf == 8 && a.f2_cin == 64)) && !a.up2 && !a.res) {
+        const size_t extra = (size_t)a.f2_cin * a.f2_cin * sizeof(T) + a.f2_cin * 4;
+        const size_t Kb = (size_t)a.Cin * sizeof(T), nslab = (Kb + SLAB - 1) / SLAB;
+        if ((size_t)a.Cout * SLAB * nslab + a.Cout * 4 + extra <= LDS_BUDGET) {
+            const hipError_t e = stream_dispatch_fused<T, KT>(p, a, s, n_cu);
+            if (e != hipErrorNotSupported) {
+                if (e == hipSuccess && fused) *fused = 1;
+                return e;
+            }
+        }
+    }
     if (!utap) {   // narrow inputs (the stem): per-lane tap, only built for the 32-channel tile
         if (KS == 3 && !p.ring && p.nf == 2) return stream_launch<T, 3, 4, 2, false, false, KT>(a, s, n_cu);
         return hipErrorNotSupported;
@@ -420,7 +510,7 @@ static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs
 }
 
 template <typename T>
-static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipStream_t s, int n_cu)
+static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipStream_t s, int n_cu, int* fused)
 {
     const int Cb = a.Cin * (int)sizeof(T);
     const bool utap = ((Cb / 16) & 3) == 0;
@@ -429,9 +519,9 @@ static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipS
     const int kt = ((Kb - (nslab - 1) * SLAB) + 63) >> 6;
     if (a.ks == 1) {
         switch (kt) {
-            case 4: return stream_dispatch<T, 1, 4>(p, utap, a, s, n_cu);
-            case 2: return stream_dispatch<T, 1, 2>(p, utap, a, s, n_cu);
-            case 1: return stream_dispatch<T, 1, 1>(p, utap, a, s, n_cu);
+            case 4: return stream_dispatch<T, 1, 4>(p, utap, a, s, n_cu, fused);
+            case 2: return stream_dispatch<T, 1, 2>(p, utap, a, s, n_cu, fused);
+            case 1: return stream_dispatch<T, 1, 1>(p, utap, a, s, n_cu, fused);
             default: return hipErrorNotSupported;
         }
     }
@@ -444,7 +534,7 @@ static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipS
 }
 
 // returns hipErrorNotSupported when the shape is not covered (caller falls back to the implicit-GEMM kernel)
-hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant)
+hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -455,7 +545,7 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
     }
     const StreamPlan p = stream_plan(dtype, a);
     if (p.nf == 0) return hipErrorNotSupported;
-    const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu) : stream_dispatch_t<__bf16>(p, a, s, n_cu);
+    const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu, fused) : stream_dispatch_t<__bf16>(p, a, s, n_cu, fused);
     if (e == hipSuccess && variant) *variant = (p.ring ? 3000 : 2000) + p.nf * 16;
     return e;
 }

@@ -34,6 +34,14 @@ struct ConvArgs {
     int tile_w, tile_h;         // halo-tile kernels: output tile shape (tile_w * tile_h <= 256)
     unsigned magic_w, magic_h;  // halo-tile kernels: 2^16 / tile_w + 1, 2^16 / (tile_w + 2) + 1 (exact division of small indices)
     int dbg;             // kernel experiments (SKY_CONV_DBG), 0 in production
+    // optional second, fused 1x1 convolution (back-to-back GEMM in the epilogue): out2 = act2(W2 * out[:, koff:koff+cin2] + b2)
+    // where `out` is this convolution's own (packed) output; honoured only by kernels that hold all Cout channels of a
+    // pixel in one workgroup -- the launcher reports through *fused whether it was
+    const void* f2_w;    // T [cout2 rows][f2_Kpad], null = nothing to fuse
+    const float* f2_bias;
+    void* f2_out;
+    int f2_cin, f2_cout, f2_ldo, f2_act, f2_Kpad, f2_koff;
+    unsigned f2_out_bytes;
     unsigned out_bytes, res_bytes;   // extents of the output / residual views in bytes (0 = 2 GiB or more)
     unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)
     // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
@@ -52,13 +60,13 @@ size_t conv_weight_rows(int cout);               // rows the packed weight / bia
 int conv_k_step(int dtype);                      // elements per 128-byte K-step
 // *variant (optional) receives which kernel ran: 1000 + N tile = implicit-GEMM tile kernel, 2000 + N_blk = streaming kernel
 // with resident weights, 3000 + N_blk = streaming kernel with the weight ring, 4000 + N_blk = halo-tile 3x3 kernel
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr, int* fused = nullptr);
 // streaming path (k_conv_stream.hip): weights resident in LDS; hipErrorNotSupported when the shape is not covered
-hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
+hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr, int* fused = nullptr);
 // halo-tile path (k_conv_halo.hip): 3x3 stride 1 with >= 128 bytes of input channels, input tile staged once in LDS;
 // variant 4000 + N_blk; hipErrorNotSupported when the shape is not covered.  SKY_CONV_HALO=0 disables, =force ignores
 // the tile-fill heuristic.
-hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr);
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr, int* fused = nullptr);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);

@@ -14,7 +14,7 @@ if len(sys.argv) > 2:
     cases = [cases[int(sys.argv[2])]]
 iters = int(os.environ.get("MICRO_ITERS", "5"))
 for cin, cout, k, s, hw in cases:
-    m = ConvolutionBlock(cin, cout, k, s).eval().set_precision(prec)
+    m = ConvolutionBlock(cin, cout, k, s, activation=os.environ.get("MICRO_NOACT") is None).eval().set_precision(prec)
     x = torch.randn(32, cin, hw, hw, device="cuda")
     m(x)
     h = m._engine([x])
