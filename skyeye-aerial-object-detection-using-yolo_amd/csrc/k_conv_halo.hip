@@ -47,10 +47,6 @@ __device__ __forceinline__ void dbg_stamp(const ConvArgs& a, unsigned long long*
 {
     if ((a.dbg & 256) && nth_tile == 1 && threadIdx.x == 0) st[slot] = __builtin_amdgcn_s_memtime();
 }
-// wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue order: the N
-// youngest -- the epilogue's stores -- may stay in flight while everything older -- the LDS-DMA -- has landed)
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
 // 16 bytes per lane: global (buffer rsrc, per-lane byte offset voff + uniform soff) -> LDS at `dst` + lane * 16
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst, int voff, int soff)
 {
@@ -347,10 +343,6 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     __syncthreads();                                   // bias staged
     if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0, first.dy, first.dx);
     if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
-    // store instructions one epilogue issues per wave (all unconditional; masked lanes only drop their data)
-    constexpr int NST = 4 * (NF / 2) * FuseGeom<T>::H + (FC ? 4 * (FC / 32) * FuseGeom<T>::H : 0);
-    static_assert(NST < 64, "vmcnt is a 6-bit counter");
-    bool after_epilogue = false;
     int nth = 0;
     for (;;) {
         int chunk = 0, q = 0;
@@ -361,10 +353,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
                 __syncthreads();                       // every wave is done with the halo tile
                 if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, chunk, st.dy, st.dx);
             }
-            // this wave's DMA (slab g, the halo) has landed.  Right after an epilogue its stores are the youngest
-            // operations: they may stay in flight, their completion latency would otherwise stall every tile
-            if (g == 0 && after_epilogue) wait_vmcnt<NST>();
-            else wait_vmcnt0();
+            wait_vmcnt0();                              // this wave's DMA (slab g, the halo) has landed (and its older stores)
             __syncthreads();                           // ... and everybody else's; compute(g - 1) is over everywhere
             int nq = q + 1, nchk = chunk;
             if (nq == 9) { nq = 0; ++nchk; }
@@ -394,7 +383,6 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
             dbg_stamp(a, stamps, nth, 43);
         }
         ++nth;
-        after_epilogue = !(a.dbg & 8);
         if (next >= ntile) break;
         tile = next; bimg = nb; y0 = ny0; x0 = nx0;
     }
@@ -515,11 +503,8 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
 
     issue_halo(tile, 0);
     int it = 0;
-    constexpr int NST = 4 * (NF / 2) * FuseGeom<T>::H;      // store instructions of one epilogue, all unconditional
     for (;;) {
-        // this wave's halo pieces have landed; the previous tile's stores (younger than them) may stay in flight
-        if (it > 0) wait_vmcnt<NST>();
-        else wait_vmcnt0();
+        wait_vmcnt0();                 // this wave's halo pieces have landed (and the previous tile's stores)
         __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer
         const int next = tile + gridDim.x;
         if (next < ntile) issue_halo(next, (it + 1) & 1);
