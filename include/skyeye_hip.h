@@ -109,7 +109,11 @@ typedef struct {
     int32_t key_channels;       /* CrossLayerAttention key/value input channels (D4 when != c_in) */
     int32_t level_channels[SKY_MAX_LEVELS]; /* FeatureNeck in_channels / DetectionHead channels */
     int32_t input_h, input_w;   /* DetectionHead.process_detections(outputs, input_shape) for a standalone head */
-    int32_t reserved[6];
+    int32_t reserved[6];        /* [0] != 0: DETECTOR / ENHANCED_DETECTOR run the build-defined "transformer prediction
+                                 * heads" (SURVEY App. A, D5): WindowedSelfAttention(window 8, C/32 heads) on P3 and P4 and
+                                 * TransformerLayer(8 heads) on P5 ahead of the detection convolutions; parameters
+                                 * head_attention.p3.* / .p4.* / .p5.*; P4 must be a multiple of 8, i.e. H, W multiples of 128.
+                                 * [1..5] must be 0. */
 } sky_config;
 
 /* One named host fp32 tensor of a state dict (names as in SURVEY Appendix C, relative to the module). */

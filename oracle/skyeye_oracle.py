@@ -331,9 +331,20 @@ def process_detections(outputs, input_shape, anchors):
     return np.concatenate(dets, 1)
 
 
-def detector_forward(P, x, nc, anchors=None, enhanced=False):
+def windowed_map(P, pre, x, window_size, num_heads):
+    """window_partition -> WindowedSelfAttention -> window_reverse on a [B, C, H, W] map (D5 wiring)."""
+    B, C, H, W = x.shape
+    ws = window_size
+    t = x.transpose(0, 2, 3, 1).reshape(B, H // ws, ws, W // ws, ws, C).transpose(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    t = windowed_self_attention(P, pre, np.ascontiguousarray(t), ws, num_heads)
+    t = t.reshape(B, H // ws, W // ws, ws, ws, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    return np.ascontiguousarray(t.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
+def detector_forward(P, x, nc, anchors=None, enhanced=False, head_attention=False):
     """SkyEyeDetector.forward in eval mode (detector.py:300-324) composed per SURVEY App. A D1/D2;
-    EnhancedSkyEyeDetector.forward (detector.py:471-501) with D4 when ``enhanced``."""
+    EnhancedSkyEyeDetector.forward (detector.py:471-501) with D4 when ``enhanced``; ``head_attention``: D5 wiring
+    (WindowedSelfAttention(8, C/32 heads) on P3 / P4, TransformerLayer(8 heads) on P5 ahead of the detection convs)."""
     anchors = DEFAULT_ANCHORS if anchors is None else anchors
     feats = backbone(P, "backbone.backbone.", x)
     neck = feature_neck(P, "neck.", feats)
@@ -342,6 +353,10 @@ def detector_forward(P, x, nc, anchors=None, enhanced=False):
         p4e = cross_layer_attention(P, "cross_attention_p5_p4.", p4, p5) + p4
         p3e = cross_layer_attention(P, "cross_attention_p4_p3.", p3, p4e) + p3
         neck = [p3e, p4e, p5]
+    if head_attention:
+        p3, p4, p5 = neck
+        neck = [windowed_map(P, "head_attention.p3.", p3, 8, p3.shape[1] // 32), windowed_map(P, "head_attention.p4.", p4, 8, p4.shape[1] // 32),
+                transformer_layer(P, "head_attention.p5.", p5, 8)]
     raw = detection_head(P, "detection_head.", neck, nc + 5, len(anchors[0]))
     det = process_detections([r.copy() for r in raw], x.shape[2:], anchors)
     return det, raw

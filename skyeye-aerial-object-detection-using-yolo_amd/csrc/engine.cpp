@@ -94,6 +94,7 @@ struct Op {
     int fused_prev = 0;    // set on that next op; skipped at run time when the producer's kernel took it
     // attention
     int heads = 0, ntok = 0, nW = 0, mask_ext = -1, v_off = 0, force_nhwc = 0;
+    int win = 0;           // attention over the win x win windows of the input map (0: over all H*W tokens of each image)
     float scale = 1.0f, r2 = 1.0f;
     TV in2;                // second activation input (CLA key/value tensor)
 };
@@ -530,7 +531,7 @@ static TV layernorm(Ctx& c, const std::string& p, const TV& x, int C)
     return y;
 }
 
-static TV attention_core(Ctx& c, const TV& qkv, int C, int heads, float scale, int bias_f, int mask_ext, int nW)
+static TV attention_core(Ctx& c, const TV& qkv, int C, int heads, float scale, int bias_f, int mask_ext, int nW, int win = 0)
 {
     const int d = C / heads;
     if (C % heads || (d != 8 && d != 16 && d != 32 && d != 64 && d != 128))
@@ -539,8 +540,9 @@ static TV attention_core(Ctx& c, const TV& qkv, int C, int heads, float scale, i
     Op op;
     op.kind = OP_ATTENTION;
     op.in = qkv; op.out = y;
-    op.heads = heads; op.ntok = qkv.H * qkv.W; op.scale = scale; op.f0 = bias_f; op.mask_ext = mask_ext; op.nW = nW;
-    op.flops = 4.0 * qkv.B * (double)op.ntok * op.ntok * C;
+    op.heads = heads; op.ntok = win ? win * win : qkv.H * qkv.W; op.scale = scale; op.f0 = bias_f; op.mask_ext = mask_ext; op.nW = nW;
+    op.win = win;
+    op.flops = 4.0 * qkv.B * (double)qkv.H * qkv.W * op.ntok * C;
     c.push(op);
     return y;
 }
@@ -578,6 +580,32 @@ static TV windowed_attention(Ctx& c, const std::string& p, const TV& x, int C, i
     }
     const int d = C / heads;
     TV att = attention_core(c, qkv, C, heads, 1.0f / std::sqrt((float)d), bias_f, mask_ext, nW);
+    return linear(c, p + "proj.weight", p + "proj.bias", att, C, C, ACT_NONE, false);
+}
+
+// WindowedSelfAttention applied to a whole [B, H, W, C] map (the reference never calls the module; this
+// is the build-defined wiring ahead of the detection convolutions): qkv and proj are per-pixel Linear layers, so only the
+// attention core needs the windows -- it addresses them in place, no window_partition / window_reverse copies.
+static TV windowed_attention_map(Ctx& c, const std::string& p, const TV& x, int C, int ws, int heads)
+{
+    const int N = ws * ws, T = (2 * ws - 1) * (2 * ws - 1);
+    if (c.emit && (x.H % ws || x.W % ws))     // (the parameter-spec dry run uses a 64 x 64 frame: geometry is checked at plan time)
+        throw Error(SKY_ERR_SHAPE, p + ": feature map " + std::to_string(x.H) + "x" + std::to_string(x.W) + " is not a multiple of the window size " + std::to_string(ws));
+    c.need(p + "relative_position_bias_table", {T, heads});
+    TV qkv = linear(c, p + "qkv.weight", p + "qkv.bias", x, C, 3 * C, ACT_NONE, false);
+    int bias_f = -1;
+    if (c.emit) {
+        const std::vector<float>& tab = c.W(p + "relative_position_bias_table").data;
+        std::vector<float> bias((size_t)heads * N * N);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                const int dy = i / ws - j / ws + ws - 1, dx = i % ws - j % ws + ws - 1;
+                const int idx = dy * (2 * ws - 1) + dx;
+                for (int h = 0; h < heads; ++h) bias[((size_t)h * N + i) * N + j] = tab[(size_t)idx * heads + h];
+            }
+        bias_f = c.upload_f32(bias);
+    }
+    TV att = attention_core(c, qkv, C, heads, 1.0f / std::sqrt((float)(C / heads)), bias_f, -1, 1, ws);
     return linear(c, p + "proj.weight", p + "proj.bias", att, C, C, ACT_NONE, false);
 }
 
@@ -917,6 +945,11 @@ static void build(Ctx& c, const Geometry& g)
                 out[0] = p3e;
                 out[1] = p4e;
             }
+            if (cf.reserved[0]) {   // D5 (build-defined "transformer prediction heads"): windows of 8 on P3 / P4, encoder layer on P5
+                out[0] = windowed_attention_map(c, "head_attention.p3.", out[0], c3, 8, c3 / 32);
+                out[1] = windowed_attention_map(c, "head_attention.p4.", out[1], c4, 8, c4 / 32);
+                out[2] = transformer(c, "head_attention.p5.", out[2], c5, 8, 4 * c5);
+            }
             head(c, "detection_head.", out, 3, cf.nc, cf.num_anchors, cf.anchors, H, W, 0);
             break;
         }
@@ -1143,8 +1176,9 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 break;
             case OP_ATTENTION:
                 SKY_HIP(launch_attention(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
-                                         op.out.ld, op.in.B, op.ntok, op.out.C, op.heads, op.scale, op.f0 >= 0 ? e.fweights[op.f0] : nullptr,
-                                         op.mask_ext >= 0 ? (const float*)ins[op.mask_ext].data : nullptr, op.nW, s));
+                                         op.out.ld, op.win ? op.in.B * (op.in.H / op.win) * (op.in.W / op.win) : op.in.B, op.ntok, op.out.C, op.heads,
+                                         op.scale, op.f0 >= 0 ? e.fweights[op.f0] : nullptr,
+                                         op.mask_ext >= 0 ? (const float*)ins[op.mask_ext].data : nullptr, op.nW, op.win, op.in.H, op.in.W, s));
                 break;
             case OP_CLA:
                 SKY_HIP(launch_cla(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.in2, ins, n_in, outs, n_out),

@@ -66,9 +66,21 @@ hipError_t launch_layernorm(int dtype, const void* x, int ldx, void* y, int ldy,
 // qkv: [G, N, 3C] (group g = image or window), head h uses channels [h*D, (h+1)*D) of each of the q | k | v thirds.
 // out[g, n, h*D + e] = sum_j softmax_j((q_n * scale) . k_j + bias[h, n, j] + mask[g % nW, n, j]) v_j[e]
 // One lane per query, keys streamed through LDS 64 at a time, online softmax in registers.
+// ws > 0: the groups are the ws x ws windows of a [B, mh, mw] feature map that stays in NHWC order (no window_partition
+// copy, attention.py:358-366 expects the caller to have made one): group g = (image, window row, window column), token n =
+// (n / ws, n % ws) inside the window; token_row() maps it to the pixel row of the map.
+__device__ __forceinline__ long token_row(int g, int n, int N, int ws, int mh, int mw)
+{
+    if (ws <= 0) return (long)g * N + n;
+    const int nwx = mw / ws, nwy = mh / ws;
+    const int wx = g % nwx, t = g / nwx, wy = t % nwy, b = t / nwy;
+    return ((long)b * mh + wy * ws + n / ws) * mw + wx * ws + n % ws;
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64) attention_kernel(const T* __restrict__ qkv, int ldq, T* __restrict__ out, int ldo, int N, int C,
-                                                       float scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW)
+                                                       float scale, const float* __restrict__ bias, const float* __restrict__ mask, int nW,
+                                                       int ws, int mh, int mw)
 {
     __shared__ float ks[64][D + 1];
     __shared__ float vs[64][D + 1];
@@ -76,20 +88,22 @@ __global__ void __launch_bounds__(64) attention_kernel(const T* __restrict__ qkv
     const int h = blockIdx.y, g = blockIdx.z;
     const int n = blockIdx.x * 64 + lane;
     const bool qok = n < N;
-    const T* base = qkv + (long)g * N * ldq;
+    const T* base = qkv;
+    const long qrow = token_row(g, qok ? n : 0, N, ws, mh, mw);
     float q[D], o[D];
 #pragma unroll
     for (int e = 0; e < D; ++e) {
-        q[e] = qok ? ld1(base + (long)n * ldq + h * D + e) * scale : 0.0f;
+        q[e] = qok ? ld1(base + qrow * ldq + h * D + e) * scale : 0.0f;
         o[e] = 0.0f;
     }
     float m = -INFINITY, l = 0.0f;
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
         const int j = j0 + lane;
+        const long jrow = token_row(g, j < N ? j : 0, N, ws, mh, mw);
         for (int e = 0; e < D; ++e) {
-            ks[lane][e] = j < N ? ld1(base + (long)j * ldq + C + h * D + e) : 0.0f;
-            vs[lane][e] = j < N ? ld1(base + (long)j * ldq + 2 * C + h * D + e) : 0.0f;
+            ks[lane][e] = j < N ? ld1(base + jrow * ldq + C + h * D + e) : 0.0f;
+            vs[lane][e] = j < N ? ld1(base + jrow * ldq + 2 * C + h * D + e) : 0.0f;
         }
         __syncthreads();
         const int jn = (N - j0) < 64 ? (N - j0) : 64;
@@ -112,17 +126,17 @@ __global__ void __launch_bounds__(64) attention_kernel(const T* __restrict__ qkv
     if (qok) {
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int e = 0; e < D; ++e) st1(out + ((long)g * N + n) * ldo + h * D + e, o[e] * inv);
+        for (int e = 0; e < D; ++e) st1(out + qrow * ldo + h * D + e, o[e] * inv);
     }
 }
 
 template <typename T>
 static hipError_t attention_t(const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale, const float* bias,
-                              const float* mask, int nW, hipStream_t s)
+                              const float* mask, int nW, int ws, int mh, int mw, hipStream_t s)
 {
     const int D = C / heads;
     const dim3 grid((N + 63) / 64, heads, G);
-#define SKY_ATT(DD) hipLaunchKernelGGL((attention_kernel<T, DD>), grid, dim3(64), 0, s, (const T*)qkv, ldq, (T*)out, ldo, N, C, scale, bias, mask, nW)
+#define SKY_ATT(DD) hipLaunchKernelGGL((attention_kernel<T, DD>), grid, dim3(64), 0, s, (const T*)qkv, ldq, (T*)out, ldo, N, C, scale, bias, mask, nW, ws, mh, mw)
     switch (D) {
         case 8: SKY_ATT(8); break;
         case 16: SKY_ATT(16); break;
@@ -136,10 +150,10 @@ static hipError_t attention_t(const void* qkv, int ldq, void* out, int ldo, int 
 }
 
 hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale,
-                            const float* bias, const float* mask, int nW, hipStream_t s)
+                            const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s)
 {
-    return dtype == 0 ? attention_t<float>(qkv, ldq, out, ldo, G, N, C, heads, scale, bias, mask, nW, s)
-                      : attention_t<__bf16>(qkv, ldq, out, ldo, G, N, C, heads, scale, bias, mask, nW, s);
+    return dtype == 0 ? attention_t<float>(qkv, ldq, out, ldo, G, N, C, heads, scale, bias, mask, nW, ws, mh, mw, s)
+                      : attention_t<__bf16>(qkv, ldq, out, ldo, G, N, C, heads, scale, bias, mask, nW, ws, mh, mw, s);
 }
 
 // ------------------------------------------------------------------------------------------------ CrossLayerAttention

@@ -105,9 +105,10 @@ hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, con
 // ---- attention side (k_attn.hip) ----
 hipError_t launch_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, const float* g, const float* b, long tokens, int C,
                             hipStream_t s);
-// qkv [G, N, 3C] -> out [G, N, C]; bias [heads, N, N] and mask [nW, N, N] optional (fp32)
+// qkv [G, N, 3C] -> out [G, N, C]; bias [heads, N, N] and mask [nW, N, N] optional (fp32).  ws > 0: the G groups are
+// the ws x ws windows of a [B, mh, mw] NHWC map addressed in place (N = ws * ws)
 hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale,
-                            const float* bias, const float* mask, int nW, hipStream_t s);
+                            const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s);
 // CrossLayerAttention core: q [B,H,W,C], kv [B,h,w,2C] (v at channel offset v_off), scores scratch [B,H,W,heads] fp32
 hipError_t launch_cla(int dtype, const void* q, int ldq, const void* kv, int ldkv, int v_off, float* scores, void* out, int ldo, int B, int H,
                       int W, int h, int w, int C, int heads, float scale, float r2, hipStream_t s);

@@ -118,6 +118,7 @@ def make_config(module, dtype=SKY_F32, device=0, **kw):
     cfg.device = device
     anchors = kw.pop("anchors", None)
     level_channels = kw.pop("level_channels", None)
+    cfg.reserved[0] = int(bool(kw.pop("head_attention", False)))     # D5 wiring (include/skyeye_hip.h, sky_config.reserved)
     for k, v in kw.items():
         setattr(cfg, k, v)
     if anchors is not None:

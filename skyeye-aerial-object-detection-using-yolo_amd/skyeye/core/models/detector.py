@@ -139,6 +139,15 @@ class SkyEyeDetector(NativeModule):
         self.neck = FeatureNeck(in_channels, width_multiple=1.0)                 # D1
         self.detection_head = DetectionHead(num_classes=self.cfg["nc"], anchors=self.cfg.get("anchors", None),
                                             channels=self.neck.out_channels)
+        # optional YAML key `head_attention: true`: the reference's "transformer prediction heads" have no
+        # call site; the build-defined wiring puts WindowedSelfAttention(window 8) on P3 / P4 and a TransformerLayer on P5
+        # ahead of the detection convolutions.  H and W must then be multiples of 128 (P4 in whole windows).
+        if self.cfg.get("head_attention", False):
+            from .attention import TransformerLayer, WindowedSelfAttention
+            c3, c4, c5 = self.neck.out_channels
+            self.head_attention = nn.ModuleDict({"p3": WindowedSelfAttention(c3, 8, c3 // 32),
+                                                 "p4": WindowedSelfAttention(c4, 8, c4 // 32),
+                                                 "p5": TransformerLayer(c5, 8)})
         self._initialize_weights()
         # the reference discovers strides with a dry run on zeros(1, ch, 64, 64) (detector.py:274,291-295)
         self.stride = torch.tensor([8, 16, 32])
@@ -148,7 +157,7 @@ class SkyEyeDetector(NativeModule):
     def _sky_config(self):
         return dict(base_channels=self.cfg.get("base_channels", 64), depth_multiple=float(self.cfg.get("depth_multiple", 1.0)),
                     width_multiple=float(self.cfg.get("width_multiple", 1.0)), nc=self.cfg["nc"], in_channels=3,
-                    anchors=self.detection_head.anchors)
+                    anchors=self.detection_head.anchors, head_attention=bool(self.cfg.get("head_attention", False)))
 
     def forward(self, x, augment=False, visualize=False):
         """eval: (detections [B, N, nc+5], [raw_P3, raw_P4, raw_P5]); train: raw list (detector.py:300-324).

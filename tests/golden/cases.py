@@ -17,11 +17,11 @@ MODELS = {
 # seeded.py: make_golden.py calibrates them once per variant on a 128x128 batch (like training would) and stores
 # them in bn_calib.npz, otherwise a 100-layer random network is chaotic and every comparison degenerates into a
 # test of overflow.  Key in bn_calib.npz: "<variant>:<state-dict name>".
-WSEED = {"skyeye_s": 101, "skyeye_m": 103, "skyeye_l": 104, "skyeye_s_enh": 109}
+WSEED = {"skyeye_s": 101, "skyeye_m": 103, "skyeye_l": 104, "skyeye_s_enh": 109, "skyeye_s_ha": 110}
 
 
 def variant_of(case):
-    return case["model"] + ("_enh" if case.get("enhanced") else "")
+    return case["model"] + ("_enh" if case.get("enhanced") else "") + ("_ha" if case.get("head_attention") else "")
 
 
 # ---- per-block cases (SURVEY 8c fixture list item 1) -----------------------
@@ -100,6 +100,13 @@ DETECTOR_CASES = [
     dict(name="enh_s_128x96", model="skyeye_s", batch=2, hw=(128, 96), seed=109, store="full", enhanced=True),
 ]
 N_SAMPLED_ROWS = 4096
+
+# ---- "transformer prediction heads" (SURVEY App. A, D5): build-defined call site of the reference's TransformerLayer /
+# WindowedSelfAttention modules; fixtures in detectors_ha.npz, BatchNorm calibration in bn_calib_ha.npz
+HA_CASES = [
+    dict(name="ha_s_128x128", model="skyeye_s", batch=2, hw=(128, 128), seed=111, store="full", head_attention=True),
+    dict(name="ha_s_128x256", model="skyeye_s", batch=1, hw=(128, 256), seed=112, store="full", head_attention=True),
+]
 
 # ---- NMS wrapper cases -----------------------------------
 # predictions are synthetic [B, N, nc+5] tensors built by tests/golden/nms_inputs.py

@@ -89,7 +89,7 @@ class ComposedDetector(nn.Module):
     state-dict keys are the reference's.
     """
 
-    def __init__(self, cfg, enhanced=False):
+    def __init__(self, cfg, enhanced=False, head_attention=False):
         super().__init__()
         self.backbone = ref_backbone.SkyEyeBackbone(cfg["base_channels"], cfg["depth_multiple"], cfg["width_multiple"])
         feats, _wrong_channels = self.backbone(torch.zeros(1, 3, 64, 64))
@@ -101,6 +101,21 @@ class ComposedDetector(nn.Module):
             c3, c4, c5 = self.neck.out_channels
             self.cross_attention_p5_p4 = make_cla_d4(c4, c5)
             self.cross_attention_p4_p3 = make_cla_d4(c3, c4)
+        self.has_head_attention = head_attention
+        if head_attention:   # D5 (build-defined call site): attention.py:244-399 modules ahead of the detection convs
+            c3, c4, c5 = self.neck.out_channels
+            self.head_attention = nn.ModuleDict({"p3": ref_attention.WindowedSelfAttention(c3, 8, c3 // 32),
+                                                 "p4": ref_attention.WindowedSelfAttention(c4, 8, c4 // 32),
+                                                 "p5": ref_attention.TransformerLayer(c5, 8)})
+
+    @staticmethod
+    def windowed(m, x, ws=8):
+        """window_partition -> WindowedSelfAttention -> window_reverse on a [B, C, H, W] map"""
+        B, C, H, W = x.shape
+        t = x.permute(0, 2, 3, 1).reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+        t = m(t)
+        t = t.reshape(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+        return t.permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x):
         feats, _ = self.backbone(x)                                       # detector.py:311
@@ -111,6 +126,9 @@ class ComposedDetector(nn.Module):
             neck = [p3e, p4e, p5]
         else:
             neck = self.neck(feats)                                       # detector.py:314
+        if self.has_head_attention:
+            neck = [self.windowed(self.head_attention["p3"], neck[0]), self.windowed(self.head_attention["p4"], neck[1]),
+                    self.head_attention["p5"](neck[2])]
         outputs = self.detection_head(neck)                               # detector.py:317
         raw = [o.clone() for o in outputs]
         det = self.detection_head.process_detections(outputs, x.shape[2:])  # detector.py:321
@@ -207,17 +225,19 @@ def gen_blocks():
     np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
 
 
-def calibrated_detector(variant, calib):
+def calibrated_detector(variant, calib, size=192, scenes=24):
     """Seeded weights + BatchNorm running statistics measured on one calibration batch of 24 structured 192x192
     scenes (momentum 1.0: running stats := batch stats), so that layer outputs are O(1) like in a trained network."""
-    enhanced = variant.endswith("_enh")
-    cfg = MODELS[variant[:-4] if enhanced else variant]
-    m = load_seeded(ComposedDetector(cfg, enhanced=enhanced), WSEED[variant])
+    ha = variant.endswith("_ha")
+    base = variant[:-3] if ha else variant
+    enhanced = base.endswith("_enh")
+    cfg = MODELS[base[:-4] if enhanced else base]
+    m = load_seeded(ComposedDetector(cfg, enhanced=enhanced, head_attention=ha), WSEED[variant])
     bns = [mod for mod in m.modules() if isinstance(mod, nn.BatchNorm2d)]
     for bn in bns:
         bn.momentum = 1.0
     m.train()
-    m(torch.from_numpy(seeded_scene(24, 192, 192, 777)).float() / 255.0)
+    m(torch.from_numpy(seeded_scene(scenes, size, size, 777)).float() / 255.0)
     m.eval()
     for k, v in m.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
@@ -264,6 +284,24 @@ def gen_detectors():
     np.savez_compressed(os.path.join(HERE, "bn_calib.npz"), **calib)
     np.savez_compressed(os.path.join(HERE, "detectors_full.npz"), **full)
     np.savez_compressed(os.path.join(HERE, "detectors_sampled.npz"), **sampled)
+
+
+def gen_head_attention():
+    """D5 wiring: ComposedDetector(head_attention=True) = reference WindowedSelfAttention (attention.py:312-399) on the
+    8x8 windows of P3 / P4 and reference TransformerLayer (:244-309) on P5, then DetectionHead."""
+    from cases import HA_CASES
+    full, calib = {}, {}
+    m = calibrated_detector("skyeye_s_ha", calib, size=256, scenes=8)
+    for case in HA_CASES:
+        h, w = case["hw"]
+        x = torch.from_numpy(seeded_scene(case["batch"], h, w, case["seed"])).float() / 255.0
+        det, raw = m(x)
+        full[f"{case['name']}.det"] = det.numpy().astype(np.float32)
+        for i, r in enumerate(raw):
+            full[f"{case['name']}.raw{i}"] = r.numpy().astype(np.float32)
+        print(f"  head-attention {case['name']} det {tuple(det.shape)} obj>0.25 {(det[..., 4] > 0.25).float().mean():.4f} raw absmax {max(float(r.abs().max()) for r in raw):.2f}")
+    np.savez_compressed(os.path.join(HERE, "bn_calib_ha.npz"), **calib)
+    np.savez_compressed(os.path.join(HERE, "detectors_ha.npz"), **full)
 
 
 def gen_nms():
@@ -327,9 +365,11 @@ def gen_eval():
 
 
 def main(argv):
-    what = set(argv) or {"blocks", "detectors", "nms", "eval"}
+    what = set(argv) or {"blocks", "detectors", "nms", "eval", "ha"}
     if "eval" in what:
         gen_eval()
+    if "ha" in what:
+        gen_head_attention()
     if "blocks" in what:
         gen_blocks()
     if "detectors" in what:

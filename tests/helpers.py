@@ -46,15 +46,35 @@ def detector_params(variant):
     from cases import MODELS, WSEED
     global _CALIB
     if _CALIB is None:
-        _CALIB = np.load(os.path.join(os.path.dirname(__file__), "golden", "bn_calib.npz"))
-    enhanced = variant.endswith("_enh")
-    cfg = MODELS[variant[:-4] if enhanced else variant]
-    P = seeded_state_for(build_detector(cfg, enhanced), WSEED[variant])
+        g = os.path.join(os.path.dirname(__file__), "golden")
+        _CALIB = {}
+        for f in ("bn_calib.npz", "bn_calib_ha.npz"):
+            z = np.load(os.path.join(g, f))
+            _CALIB.update({k: z[k] for k in z.files})
+    P = seeded_state_for(build_detector(variant_cfg(variant), variant_enhanced(variant)), WSEED[variant])
     for k in list(P):
         ck = f"{variant}:{k}"
-        if ck in _CALIB.files:
+        if ck in _CALIB:
             P[k] = _CALIB[ck]
     return P
+
+
+def variant_enhanced(variant):
+    base = variant[:-3] if variant.endswith("_ha") else variant
+    return base.endswith("_enh")
+
+
+def variant_cfg(variant):
+    """cases.MODELS entry of a detector variant name ("skyeye_s", "skyeye_s_enh", "skyeye_s_ha", ...)."""
+    from cases import MODELS
+    ha = variant.endswith("_ha")
+    base = variant[:-3] if ha else variant
+    if base.endswith("_enh"):
+        base = base[:-4]
+    cfg = dict(MODELS[base])
+    if ha:
+        cfg["head_attention"] = True
+    return cfg
 
 
 def load_seeded(module, seed):

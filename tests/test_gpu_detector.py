@@ -6,24 +6,33 @@ import numpy as np
 import pytest
 import torch
 
-from cases import DETECTOR_CASES, MODELS, variant_of
-from helpers import build_detector, detector_params
+from cases import DETECTOR_CASES, HA_CASES, MODELS, variant_of
+from helpers import build_detector, detector_params, variant_cfg, variant_enhanced
 from parity import close, det_close, level_scales
 from seeded import seeded_scene
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
-DET_FULL = np.load(os.path.join(G, "detectors_full.npz"))
+_FULL = np.load(os.path.join(G, "detectors_full.npz"))
+_HA = np.load(os.path.join(G, "detectors_ha.npz"))       # D5 wiring (head attention), tests/golden/make_golden.py ha
+
+
+class _Full:
+    def __getitem__(self, k):
+        return _HA[k] if k in _HA.files else _FULL[k]
+
+
+DET_FULL = _Full()
 DET_SAMPLED = np.load(os.path.join(G, "detectors_sampled.npz"))
 
-CASES = list(DETECTOR_CASES)
+CASES = list(DETECTOR_CASES) + list(HA_CASES)
 _MODELS = {}
 
 
 def model_for(case):
     v = variant_of(case)
     if v not in _MODELS:
-        m = build_detector(MODELS[case["model"]], case.get("enhanced", False))
+        m = build_detector(variant_cfg(v), variant_enhanced(v))
         m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params(v).items()}, strict=True)
         _MODELS[v] = m.eval()
     return _MODELS[v]
@@ -43,7 +52,7 @@ def run(case, precision, as_uint8=False):
 def tol_for(case):
     # the cross-layer attention of the Enhanced detector (column softmax over image rows, x4) amplifies fp32
     # summation-order differences ~2.5x more than the plain graph; the oracle itself sits at 2.5e-4 from torch there
-    return 3e-4 if case.get("enhanced") else 1e-4
+    return 3e-4 if case.get("enhanced") or case.get("head_attention") else 1e-4
 
 
 def check_against_fixture(case, det, raw, tol):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import BLOCK_CASES, DETECTOR_CASES, MODELS, NMS_CASES, variant_of
+from cases import BLOCK_CASES, DETECTOR_CASES, MODELS, NMS_CASES, variant_of, HA_CASES
 from nms_inputs import make_predictions
 from seeded import seeded_input, seeded_scene, seeded_tensor
 
@@ -21,6 +21,7 @@ from parity import close, det_close, level_scales
 G = os.path.join(os.path.dirname(__file__), "golden")
 BLOCKS = np.load(os.path.join(G, "blocks.npz"))
 DET_FULL = np.load(os.path.join(G, "detectors_full.npz"))
+DET_HA = np.load(os.path.join(G, "detectors_ha.npz"))
 DET_SAMPLED = np.load(os.path.join(G, "detectors_sampled.npz"))
 NMS = np.load(os.path.join(G, "nms.npz"))
 
@@ -80,7 +81,20 @@ def oracle_detector(case):
     P = detector_params(variant_of(case))
     h, w = case["hw"]
     x = seeded_scene(case["batch"], h, w, case["seed"]).astype(np.float32) / np.float32(255.0)
-    return O.detector_forward(P, x, cfg["nc"], enhanced=case.get("enhanced", False))
+    return O.detector_forward(P, x, cfg["nc"], enhanced=case.get("enhanced", False), head_attention=case.get("head_attention", False))
+
+
+@pytest.mark.parametrize("case", HA_CASES, ids=[c["name"] for c in HA_CASES])
+def test_head_attention_detector_matches_reference_composition(case):
+    """D5 wiring: the reference's own WindowedSelfAttention / TransformerLayer modules composed ahead of
+    the detection convolutions (tests/golden/make_golden.py: ComposedDetector(head_attention=True))."""
+    det, raw = oracle_detector(case)
+    ref = DET_HA[f"{case['name']}.det"]
+    assert det.shape == ref.shape
+    tol = 3e-4            # softmax attention amplifies summation-order differences like the cross-layer attention does
+    det_close(det, ref, level_scales(case["hw"]), tol)
+    for i, r in enumerate(raw):
+        close(r, DET_HA[f"{case['name']}.raw{i}"], rtol=5e-5 * tol / 1e-4)
 
 
 @pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
