@@ -50,10 +50,11 @@ def parse():
 
 
 def build_model(name, precision, device):
-    from cases import MODELS
-    from helpers import build_detector, detector_params
+    """name: a tests/golden/cases.py variant -- skyeye_s / _m / _l, skyeye_s_enh (cross-layer attention), skyeye_s_ha
+    (config 3: windowed attention on P3 / P4 + transformer layer on P5 ahead of the detection convs)."""
+    from helpers import build_detector, detector_params, variant_cfg, variant_enhanced
     P = detector_params(name)
-    model = build_detector(MODELS[name])
+    model = build_detector(variant_cfg(name), variant_enhanced(name))
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()}, strict=True)
     model.eval().set_precision(precision)
     return model, P

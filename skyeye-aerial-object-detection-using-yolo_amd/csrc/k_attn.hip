@@ -8,12 +8,13 @@
 //                          out[b,c,y,x] = R^2 * softmax_y(sum_{c' in head} Q*K / sqrt(Cq))[b,head(c),y,x] * V[b,c,y,x]
 //                          (SURVEY App. B.9).
 // All projections (QKV, out_proj, FFN, 1x1 convs with bias) run on the streaming convolution kernel: in NHWC a token
-// IS a pixel row.  These kernels are first, correct versions (fp32 VALU math, one query per lane); the MFMA
-// flash-style core is listed as next in DESIGN.md.
+// IS a pixel row.  attention_kernel is the general core (fp32 VALU math, one query per lane: exact mode, windows, bias,
+// mask); attention_mfma_kernel is the flash-style MFMA core of the bf16 engine for plain attention over all tokens.
 #include "sky_kernels.h"
 
 #include <hip/hip_bf16.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace sky {
 
@@ -130,6 +131,155 @@ __global__ void __launch_bounds__(64) attention_kernel(const T* __restrict__ qkv
     }
 }
 
+// ------------------------------------------------------------------------------------------------ MFMA flash core
+// softmax(Q K^T * scale) V for the bf16 engine without bias / mask (TransformerLayer, attention.py:282-309), on the matrix
+// cores.  A workgroup (4 waves) owns 64 queries of one (image, head); wave w owns 16 of them.  Keys are walked 64 at a time:
+//   * S^T = K Q^T with v_mfma_f32_16x16x32_bf16: A = K rows from LDS (XOR-swizzled 16-byte chunks), B = Q straight from
+//     global in fragment order (kept in registers for the whole kernel).  In the D layout lane (n, g) then holds, for QUERY
+//     n = lane & 15, the keys 4g..4g+3 of each 16-key tile: the softmax reductions over keys are in-lane plus two
+//     cross-lane-group steps, and the running maximum / sum / rescale factor of a query live in the lanes that own it;
+//   * O^T = V^T P^T: the B operand of K-step ks (32 keys) is lane (n, g)'s OWN eight probabilities of tiles 2ks, 2ks+1
+//     packed to bf16 -- no data movement --, provided V^T is staged in LDS with the matching key order
+//     slot(key) = ks*32 + g*8 + t*4 + j for key = (2ks + t)*16 + 4g + j;
+//   * O^T's D layout gives lane (n, g) the channels e = 16*tile + 4g..4g+3 of its query: 8-byte stores.
+// Online softmax in fp32 (exp on v_exp_f32); P and V enter the second product as bf16.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_att_t;
+
+// WIN: the groups are ws x ws windows of a [B, mh, mw] map addressed in place (token_row) and the relative position bias
+// [heads, N, N] (+ optional mask [nW, N, N]) is added to the scaled scores (WindowedSelfAttention, attention.py:377-392).
+template <int D, bool WIN>
+__global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __restrict__ qkv, int ldq, __bf16* __restrict__ out, int ldo, int N,
+                                                             int C, float scale, const float* __restrict__ bias, const float* __restrict__ mask,
+                                                             int nW, int ws, int mh, int mw)
+{
+    constexpr int KT = D / 32;                  // K-steps of the first product
+    constexpr int OT = D / 16;                  // 16-channel tiles of the output
+    constexpr int KROW = D * 2;                 // bytes of one K row in LDS
+    constexpr int CM = (D / 8 < 8 ? D / 8 : 8) - 1;   // chunk-swizzle mask inside one K row (rows of 32 channels have 4 chunks)
+    __shared__ __attribute__((aligned(16))) char kl[64 * KROW];       // K tile [64 keys][D], chunks swizzled by (key >> 1) & 7
+    __shared__ __attribute__((aligned(16))) char vl[D * 128];         // V^T tile [D channels][64 key slots], same swizzle by channel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;                          // b: image, or window when WIN
+    const int q = blockIdx.x * 64 + wave * 16 + n;                     // this lane's query
+    const bool qok = q < N;
+    const long qrow = WIN ? token_row(b, qok ? q : 0, N, ws, mh, mw) : (long)b * N + q;
+
+    u32x4_t qf[KT];                                                    // B operand of S^T: Q[q][ks*32 + g*8 .. +8]
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks)
+        qf[ks] = qok ? *reinterpret_cast<const u32x4_t*>(qkv + qrow * ldq + h * D + ks * 32 + g * 8) : u32x4_t{0u, 0u, 0u, 0u};
+
+    f32x4_t o[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.0f;
+    const float sl2 = scale * 1.4426950408889634f;                     // exp(x * scale) = exp2(x * scale * log2 e)
+
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        __syncthreads();                                               // previous tiles are consumed
+        // ---- stage K (row-major, swizzled) and V^T (permuted key slots) ----
+        for (int idx = tid; idx < 64 * (D / 8); idx += 256) {
+            const int key = idx / (D / 8), c = idx - key * (D / 8);    // 16-byte chunk c (8 channels) of key row `key`
+            const int j = j0 + key;
+            u32x4_t kv = u32x4_t{0u, 0u, 0u, 0u}, vv = kv;
+            if (j < N) {
+                const long jrow = WIN ? token_row(b, j, N, ws, mh, mw) : (long)b * N + j;
+                kv = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + C + h * D + c * 8);
+                vv = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + 2 * C + h * D + c * 8);
+            }
+            *reinterpret_cast<u32x4_t*>(kl + key * KROW + (((c & ~CM) | ((c ^ (key >> 1)) & CM)) << 4)) = kv;
+            const int T = key >> 4, r16 = key & 15;
+            const int slot = (T >> 1) * 32 + (r16 >> 2) * 8 + (T & 1) * 4 + (r16 & 3);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = c * 8 + e;
+                const unsigned short val = (unsigned short)(vv[e >> 1] >> ((e & 1) * 16));
+                const int chunk = slot >> 3;                           // 16-byte chunk of the V^T row, swizzled by the channel
+                *reinterpret_cast<unsigned short*>(vl + ch * 128 + (((chunk ^ (ch >> 1)) & 7) << 4) + (slot & 7) * 2) = val;
+            }
+        }
+        __syncthreads();
+        // ---- S^T tiles: keys 16T + 4g + r of this 64-key block x query n ----
+        f32x4_t sT[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            sT[T] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                const int key = T * 16 + n;                            // A operand row of this lane
+                const int c = ks * 4 + g;
+                const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(kl + key * KROW + (((c & ~CM) | ((c ^ (key >> 1)) & CM)) << 4));
+                sT[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, kf), __builtin_bit_cast(bf16x8_att_t, qf[ks]), sT[T], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for query n (log2 domain) ----
+        float bm = -INFINITY;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j0 + T * 16 + 4 * g + r;
+                float add = 0.0f;                                      // bias[h][query][key] (+ mask[window % nW][query][key])
+                if (WIN && qok && key < N) {
+                    if (bias) add = bias[((long)h * N + q) * N + key];
+                    if (mask) add += mask[((long)(b % nW) * N + q) * N + key];
+                }
+                sT[T][r] = key < N ? sT[T][r] * sl2 + add * 1.4426950408889634f : -INFINITY;
+                bm = sT[T][r] > bm ? sT[T][r] : bm;
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 16));
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mn = bm > m ? bm : m;
+        const float corr = __builtin_amdgcn_exp2f(m - mn);             // m = -inf on the first block: exp2(-inf) = 0
+        float bs = 0.0f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sT[T][r] = __builtin_amdgcn_exp2f(sT[T][r] - mn);
+                bs += sT[T][r];
+            }
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        l = l * corr + bs;
+        m = mn;
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t][r] *= corr;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4_t pf;                                                // this lane's probabilities of tiles 2ks, 2ks+1 as 8 bf16
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4_t& src = sT[2 * ks + (e >> 1)];
+                const __bf16 lo = (__bf16)src[(e & 1) * 2], hi = (__bf16)src[(e & 1) * 2 + 1];
+                pf[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+                const int ch = t * 16 + n;                             // A operand row: channel
+                const int chunk = ks * 4 + g;
+                const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(vl + ch * 128 + (((chunk ^ (ch >> 1)) & 7) << 4));
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, vf), __builtin_bit_cast(bf16x8_att_t, pf), o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (qok) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+            const __bf16 a0 = (__bf16)(o[t][0] * inv), a1 = (__bf16)(o[t][1] * inv), a2 = (__bf16)(o[t][2] * inv), a3 = (__bf16)(o[t][3] * inv);
+            uint2 w;
+            w.x = (unsigned int)__builtin_bit_cast(unsigned short, a0) | ((unsigned int)__builtin_bit_cast(unsigned short, a1) << 16);
+            w.y = (unsigned int)__builtin_bit_cast(unsigned short, a2) | ((unsigned int)__builtin_bit_cast(unsigned short, a3) << 16);
+            *reinterpret_cast<uint2*>(out + qrow * ldo + h * D + t * 16 + 4 * g) = w;
+        }
+    }
+}
+
 template <typename T>
 static hipError_t attention_t(const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale, const float* bias,
                               const float* mask, int nW, int ws, int mh, int mw, hipStream_t s)
@@ -152,6 +302,19 @@ static hipError_t attention_t(const void* qkv, int ldq, void* out, int ldo, int 
 hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale,
                             const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s)
 {
+    const int D = heads > 0 ? C / heads : 0;
+    const bool no_mfma = getenv("SKY_ATTN_VALU") != nullptr;              // A/B switch (read per launch: tests toggle it)
+    if (dtype != 0 && !no_mfma && N >= 64 && (D == 32 || D == 64 || D == 128) && ldq % 8 == 0 && ldo % 4 == 0 && C % 8 == 0) {
+        const dim3 grid((N + 63) / 64, heads, G);
+        const bool win = ws > 0 || bias || mask;
+#define SKY_FLASH(DD, WW) hipLaunchKernelGGL((attention_mfma_kernel<DD, WW>), grid, dim3(256), 0, s, (const __bf16*)qkv, ldq, (__bf16*)out, ldo, N, C, \
+                                             scale, bias, mask, nW > 0 ? nW : 1, ws, mh, mw)
+        if (D == 32) { if (win) SKY_FLASH(32, true); else SKY_FLASH(32, false); }
+        else if (D == 64) { if (win) SKY_FLASH(64, true); else SKY_FLASH(64, false); }
+        else { if (win) SKY_FLASH(128, true); else SKY_FLASH(128, false); }
+#undef SKY_FLASH
+        return hipGetLastError();
+    }
     return dtype == 0 ? attention_t<float>(qkv, ldq, out, ldo, G, N, C, heads, scale, bias, mask, nW, ws, mh, mw, s)
                       : attention_t<__bf16>(qkv, ldq, out, ldo, G, N, C, heads, scale, bias, mask, nW, ws, mh, mw, s);
 }
