@@ -189,6 +189,14 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
             int32_t* counts, void* stream);
 int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream);
 
+/* letterbox (core/data/augmentation.py:442-496): src uint8 [H0, W0, 3] on the device -> resize to (new_h, new_w) with
+ * OpenCV's 8-bit INTER_LINEAR arithmetic -> placed at (top, left) of a (H1, W1) frame filled with pad_value (114).  dst is
+ * [H1, W1, 3] (dst_chw = 0, the reference's return layout) or [3, H1, W1] (dst_chw = 1; reverse_channels = 1 also flips
+ * BGR <-> RGB, detect.py:133), i.e. directly the engine's uint8 input.  The caller computes the geometry
+ * (skyeye.core.data.augmentation.letterbox does, with the reference's rounding).  Asynchronous on `stream`. */
+int sky_letterbox(sky_handle* h, const uint8_t* src, int H0, int W0, uint8_t* dst, int H1, int W1, int new_h, int new_w,
+                  int top, int left, int pad_value, int dst_chw, int reverse_channels, void* stream);
+
 /* box_iou (metrics.py:17-44), the pairwise IoU of the evaluation accounting (validate.py:71-108 process_batch):
  * out[n, m] fp32 on the device.  box1_is_4xn = 1 reads box1 as [4, n] -- the indexing the file actually performs
  *  --, 0 as [n, 4]; box2 is [m, 4], corners (x1, y1, x2, y2).  Asynchronous on `stream`. */

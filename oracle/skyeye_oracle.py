@@ -424,3 +424,41 @@ def process_batch(detections, labels, iouv):
         for p in by_lab.values():
             correct[p[2], t] = True
     return correct
+
+
+# --------------------------------------------------------------------------- letterbox
+def _lb_taps(n_dst, n_src):
+    """OpenCV 8-bit INTER_LINEAR taps: first source index and the two coefficients (x 2048) per destination index."""
+    scale = np.float64(n_src) / np.float64(n_dst)
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo = s < 0
+    s[lo], f[lo] = 0, 0.0
+    hi = s >= n_src - 1
+    s[hi], f[hi] = n_src - 1, 0.0
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)
+    a1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+    return s, a0, a1
+
+
+def letterbox_pixels(img, new_h, new_w, top, bottom, left, right, pad=114):
+    """uint8 [H, W, 3] -> cv2.resize(INTER_LINEAR) restated (fixed point, see csrc/k_misc.hip) + constant border."""
+    img = np.asarray(img, np.uint8)
+    H0, W0 = img.shape[:2]
+    if (new_h, new_w) == (H0, W0):
+        res = img
+    else:
+        xs, ax0, ax1 = _lb_taps(new_w, W0)
+        ys, by0, by1 = _lb_taps(new_h, H0)
+        x1 = np.minimum(xs + 1, W0 - 1)
+        y1 = np.minimum(ys + 1, H0 - 1)
+        src = img.astype(np.int64)
+        rows0 = src[ys][:, xs] * ax0[None, :, None] + src[ys][:, x1] * ax1[None, :, None]
+        rows1 = src[y1][:, xs] * ax0[None, :, None] + src[y1][:, x1] * ax1[None, :, None]
+        o = (((by0[:, None, None] * (rows0 >> 4)) >> 16) + ((by1[:, None, None] * (rows1 >> 4)) >> 16) + 2) >> 2
+        res = np.clip(o, 0, 255).astype(np.uint8)
+    out = np.full((new_h + top + bottom, new_w + left + right, 3), pad, np.uint8)
+    out[top:top + new_h, left:left + new_w] = res
+    return out

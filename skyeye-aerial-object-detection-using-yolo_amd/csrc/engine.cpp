@@ -1554,6 +1554,19 @@ int sky_box_iou(sky_handle* h, const float* box1, int n, int box1_is_4xn, const 
     });
 }
 
+int sky_letterbox(sky_handle* h, const uint8_t* src, int H0, int W0, uint8_t* dst, int H1, int W1, int new_h, int new_w, int top, int left,
+                  int pad_value, int dst_chw, int reverse_channels, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!src || !dst) throw Error(SKY_ERR_INVALID, "sky_letterbox: null argument");
+        if (H0 < 1 || W0 < 1 || new_h < 1 || new_w < 1 || top < 0 || left < 0 || top + new_h > H1 || left + new_w > W1)
+            throw Error(SKY_ERR_SHAPE, "sky_letterbox: the resized frame plus its border must fit the destination");
+        SKY_HIP(launch_letterbox(src, H0, W0, dst, H1, W1, new_h, new_w, top, left, pad_value & 255, dst_chw ? 1 : 0, reverse_channels ? 1 : 0,
+                                 (hipStream_t)stream));
+    });
+}
+
 int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream)
 {
     if (!h) return SKY_ERR_INVALID;

@@ -579,4 +579,69 @@ hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, con
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ letterbox
+// letterbox (reference core/data/augmentation.py:442-496): resize the uint8 HWC frame to (nh, nw) with cv2.resize
+// INTER_LINEAR, then constant border (top, left, rest) to (H1, W1).  The resize restates OpenCV's fixed-point 8-bit
+// bilinear (imgproc resize.cpp, INTER_RESIZE_COEF_BITS = 11): source coordinate (d + 0.5) * scale - 0.5, taps clamped at the
+// edges, coefficients rounded to 1/2048, horizontal pass in int, vertical pass
+// ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  cv2 is not installed in the build container and the
+// reference holds no image fixtures: PARITY UNPINNED against OpenCV, pinned against oracle/.  One thread per output pixel
+// (3 channels); dst is HWC (the reference's return layout) or CHW with optional channel reversal (detect.py:133:
+// transpose((2, 0, 1))[::-1]), so the frame can go straight into the engine.
+__device__ __forceinline__ void lb_tap(int d, double scale, int n, int& s0, int& a0, int& a1)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) { si = 0; f = 0.0f; }
+    if (si >= n - 1) { si = n - 1; f = 0.0f; }
+    s0 = si;
+    a0 = (int)rintf((1.0f - f) * 2048.0f);
+    a1 = (int)rintf(f * 2048.0f);
+}
+
+__global__ void letterbox_kernel(const unsigned char* __restrict__ src, int H0, int W0, unsigned char* __restrict__ dst, int H1, int W1, int nh,
+                                 int nw, int top, int left, int pad, int chw, int rev)
+{
+    const long total = (long)H1 * W1;
+    const double sx = (double)W0 / (double)nw, sy = (double)H0 / (double)nh;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W1), y = (int)(i / W1);
+        const int rx = x - left, ry = y - top;
+        int v[3] = {pad, pad, pad};
+        if (rx >= 0 && rx < nw && ry >= 0 && ry < nh) {
+            if (nw == W0 && nh == H0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = src[((long)ry * W0 + rx) * 3 + c];
+            } else {
+                int x0, ax0, ax1, y0, by0, by1;
+                lb_tap(rx, sx, W0, x0, ax0, ax1);
+                lb_tap(ry, sy, H0, y0, by0, by1);
+                const int x1 = x0 < W0 - 1 ? x0 + 1 : x0, y1 = y0 < H0 - 1 ? y0 + 1 : y0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int r0 = src[((long)y0 * W0 + x0) * 3 + c] * ax0 + src[((long)y0 * W0 + x1) * 3 + c] * ax1;
+                    const int r1 = src[((long)y1 * W0 + x0) * 3 + c] * ax0 + src[((long)y1 * W0 + x1) * 3 + c] * ax1;
+                    int o = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                    v[c] = o < 0 ? 0 : (o > 255 ? 255 : o);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cc = rev ? 2 - c : c;
+            if (chw) dst[((long)cc * H1 + y) * W1 + x] = (unsigned char)v[c];
+            else dst[((long)y * W1 + x) * 3 + cc] = (unsigned char)v[c];
+        }
+    }
+}
+
+hipError_t launch_letterbox(const unsigned char* src, int H0, int W0, unsigned char* dst, int H1, int W1, int nh, int nw, int top, int left,
+                            int pad, int chw, int rev, hipStream_t s)
+{
+    const long total = (long)H1 * W1;
+    hipLaunchKernelGGL(letterbox_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, src, H0, W0, dst, H1, W1, nh, nw, top, left, pad, chw, rev);
+    return hipGetLastError();
+}
+
 }  // namespace sky

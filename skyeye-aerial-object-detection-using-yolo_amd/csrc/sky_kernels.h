@@ -82,6 +82,11 @@ hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int 
 hipError_t launch_upsample(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int Ho,
                            int Wo, hipStream_t s);
 
+// letterbox (augmentation.py:442-496): uint8 HWC frame -> resized (nh, nw, bilinear, OpenCV's 8-bit fixed point) + constant
+// border, written HWC or CHW (optionally with reversed channel order)
+hipError_t launch_letterbox(const unsigned char* src, int H0, int W0, unsigned char* dst, int H1, int W1, int nh, int nw, int top, int left,
+                            int pad, int chw, int rev, hipStream_t s);
+
 // DetectionHead.process_detections alone (detector.py:88-145): raw [B,na,gh,gw,no] -> det rows of one level
 hipError_t launch_decode(const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
                          float stride_px, const float* anchor_wh /*host, na*2, already * stride*/, hipStream_t s);

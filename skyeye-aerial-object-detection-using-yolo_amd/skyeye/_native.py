@@ -55,7 +55,7 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_box_iou", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
+           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
 _lib = None
 
@@ -100,6 +100,7 @@ def lib():
     L.sky_nms.argtypes = [vp, vp, ip, ip, ip, ctypes.POINTER(SkyNmsParams), vp, vp, vp]
     L.sky_nms_fetch.argtypes = [vp, vp, ip, vp, vp]
     L.sky_box_iou.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp]
+    L.sky_letterbox.argtypes = [vp, vp, ip, ip, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     _lib = L
     return L
 
