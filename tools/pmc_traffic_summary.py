@@ -20,7 +20,7 @@ for k, v in agg.items():
     m = re.search(r"conv_stream_kernelI(DF16b|f)Li(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)E", k)
     name = k.split("(")[0][:100]
     variant = None
-    m2 = re.search(r"conv_stream_kernel<.*?(\d), (\d), (true|false), (true|false), (\d)>", k)
+    m2 = re.search(r"conv_stream_kernel<.*?(\d), (\d), (true|false), (true|false), (\d)(?:, (?:true|false), \d+)?>", k)
     if m:
         variant = (3000 if m.group(5) == "1" else 2000) + int(m.group(4)) * 16
     elif m2:
