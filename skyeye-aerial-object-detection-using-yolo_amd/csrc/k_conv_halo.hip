@@ -341,8 +341,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
     const int G = nchunk * 9;
     const TapStep first = tap_step<S2>(0);
     __syncthreads();                                   // bias staged
+    const TapStep second = tap_step<S2>(1);
     if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0, first.dy, first.dx);
-    if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
+    if (!(a.dbg & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
     int nth = 0;
     for (;;) {
         int chunk = 0, q = 0;
@@ -358,7 +359,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
             int nq = q + 1, nchk = chunk;
             if (nq == 9) { nq = 0; ++nchk; }
             dbg_stamp(a, stamps, nth, 1 + 2 * g);
-            if (g + 1 < G && !(a.dbg & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
+            // slabs 0 AND 1 of a tile are requested ahead of it (prologue / before the previous epilogue): behind that
+            // epilogue's stores the first tap's DMA issue would stall for the length of the store drain (clock stamps)
+            if (g > 0 && g + 1 < G && !(a.dbg & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
             if (!(a.dbg & 1)) compute_tap(st.tap, g & 1);
             dbg_stamp(a, stamps, nth, 2 + 2 * g);
             q = nq;
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
             __syncthreads();
             dbg_stamp(a, stamps, nth, 40);
             if (!(a.dbg & 2)) issue_halo(nb, ny0, nx0, 0, first.dy, first.dx);
-            if (!(a.dbg & 4)) issue_w(first.tap, 0, 0);
+            if (!(a.dbg & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
         }
         dbg_stamp(a, stamps, nth, 41);
         if (!(a.dbg & 8)) epilogue_act(bimg, y0, x0);
