@@ -209,17 +209,19 @@ def main():
         from oracle import skyeye_oracle as O
         O.set_threads(min(64, os.cpu_count() or 1))          # beyond ~64 threads the band-parallel C port stops scaling
         Pc = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()}
-        from cases import MODELS
-        nc = MODELS[a.model]["nc"]
+        from helpers import variant_cfg, variant_enhanced
+        vcfg = variant_cfg(a.model)
+        nc = vcfg["nc"]
+        okw = dict(enhanced=variant_enhanced(a.model), head_attention=bool(vcfg.get("head_attention", False)))
         xs = frames_np[:1].astype(np.float32) / np.float32(255.0)
         t1 = time.perf_counter()
-        d, _ = O.detector_forward(Pc, xs, nc)
+        d, _ = O.detector_forward(Pc, xs, nc, **okw)
         O.non_max_suppression(d, a.conf, a.iou)
         one = time.perf_counter() - t1
         n = int(max(1, min(8, 20.0 / max(one, 1e-3))))
         t1 = time.perf_counter()
         for i in range(n):
-            d, _ = O.detector_forward(Pc, frames_np[i % B:i % B + 1].astype(np.float32) / np.float32(255.0), nc)
+            d, _ = O.detector_forward(Pc, frames_np[i % B:i % B + 1].astype(np.float32) / np.float32(255.0), nc, **okw)
             O.non_max_suppression(d, a.conf, a.iou)
         cpu_dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(n / cpu_dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port",
