@@ -189,6 +189,22 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
             int32_t* counts, void* stream);
 int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream);
 
+/* Export of the engine's own weight file (the reference's export.py is empty and fuse_conv_and_bn,
+ * general imports at utils/__init__.py:22-25, is undefined): the convolution weights exactly as the kernels read them --
+ * BatchNorm folded (w * gamma / sqrt(var + 1e-5), bias = beta - mean * scale, blocks.py:39-41 fused_forward), K ordered
+ * (ky, kx, cin) and padded to `kpad`, rows padded to the N tile, element type of the engine -- plus the fp32 bias rows.
+ * Valid after sky_plan.  sky_packed_read copies to host buffers (either may be NULL). */
+typedef struct sky_packed_desc {
+    char name[128];        /* state-dict name of the source weight (the first one for fused GEMMs such as cv1|cv2) */
+    int32_t rows, cout;    /* packed rows (>= cout, zero rows beyond) */
+    int32_t kpad;          /* elements per row */
+    int32_t kernel_size, cin;
+    int32_t dtype;         /* sky_dtype of the elements */
+} sky_packed_desc;
+int sky_num_packed(const sky_handle* h);
+int sky_packed_info(const sky_handle* h, int i, sky_packed_desc* out);
+int sky_packed_read(sky_handle* h, int i, void* weights_host, size_t weight_bytes, float* bias_host, size_t bias_count);
+
 /* letterbox (core/data/augmentation.py:442-496): src uint8 [H0, W0, 3] on the device -> resize to (new_h, new_w) with
  * OpenCV's 8-bit INTER_LINEAR arithmetic -> placed at (top, left) of a (H1, W1) frame filled with pad_value (114).  dst is
  * [H1, W1, 3] (dst_chw = 0, the reference's return layout) or [3, H1, W1] (dst_chw = 1; reverse_channels = 1 also flips

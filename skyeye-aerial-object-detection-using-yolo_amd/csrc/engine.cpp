@@ -104,6 +104,9 @@ struct DevConv {
     float* bias = nullptr;
     int Kpad = 0;
     size_t bytes = 0;
+    // description for sky_packed_* (export of the engine's own weight file)
+    int rows = 0, cout = 0, ks = 0, cin = 0;
+    std::string name;      // state-dict name of the (first) source weight
 };
 
 struct Buffer {
@@ -320,6 +323,8 @@ struct Ctx {
         DevConv d;
         d.Kpad = Kpad;
         d.bytes = packed.size() * e.esize();
+        d.rows = (int)rows; d.cout = cout; d.ks = ks; d.cin = cin_store;
+        d.name = srcs.empty() ? std::string() : srcs[0].wname;
         SKY_HIP(hipMalloc(&d.w, d.bytes));
         e.owned.push_back(d.w);
         if (e.dtype == SKY_F32) {
@@ -1505,6 +1510,43 @@ int sky_plan_stats(const sky_handle* h, double* flops, double* activation_bytes,
     if (weight_bytes) *weight_bytes = h->e.weight_bytes;
     if (launches) *launches = (int32_t)h->e.ops.size();
     return SKY_OK;
+}
+
+int sky_num_packed(const sky_handle* h)
+{
+    if (!h || !h->e.planned) return SKY_ERR_STATE;
+    return (int)h->e.convs.size();
+}
+
+int sky_packed_info(const sky_handle* h, int i, sky_packed_desc* out)
+{
+    if (!h || !out) return SKY_ERR_INVALID;
+    if (!h->e.planned) return SKY_ERR_STATE;
+    if (i < 0 || i >= (int)h->e.convs.size()) return SKY_ERR_INVALID;
+    const DevConv& d = h->e.convs[i];
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", d.name.c_str());
+    out->rows = d.rows; out->cout = d.cout; out->kpad = d.Kpad; out->kernel_size = d.ks; out->cin = d.cin;
+    out->dtype = h->e.dtype;
+    return SKY_OK;
+}
+
+int sky_packed_read(sky_handle* h, int i, void* weights_host, size_t weight_bytes, float* bias_host, size_t bias_count)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!h->e.planned) throw Error(SKY_ERR_STATE, "sky_packed_read: plan the graph first (weights are packed at plan time)");
+        if (i < 0 || i >= (int)h->e.convs.size()) throw Error(SKY_ERR_INVALID, "sky_packed_read: index out of range");
+        const DevConv& d = h->e.convs[i];
+        if (weights_host) {
+            if (weight_bytes < d.bytes) throw Error(SKY_ERR_INVALID, "sky_packed_read: weight buffer too small");
+            SKY_HIP(hipMemcpy(weights_host, d.w, d.bytes, hipMemcpyDeviceToHost));
+        }
+        if (bias_host) {
+            if (bias_count < (size_t)d.rows) throw Error(SKY_ERR_INVALID, "sky_packed_read: bias buffer too small");
+            SKY_HIP(hipMemcpy(bias_host, d.bias, (size_t)d.rows * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    });
 }
 
 int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms_params* p, float* out, int32_t* counts, void* stream)

@@ -55,9 +55,14 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
+           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
 _lib = None
+
+
+class SkyPackedDesc(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("rows", ctypes.c_int32), ("cout", ctypes.c_int32), ("kpad", ctypes.c_int32),
+                ("kernel_size", ctypes.c_int32), ("cin", ctypes.c_int32), ("dtype", ctypes.c_int32)]
 
 
 class SkyEyeNativeError(RuntimeError):
@@ -100,6 +105,9 @@ def lib():
     L.sky_nms.argtypes = [vp, vp, ip, ip, ip, ctypes.POINTER(SkyNmsParams), vp, vp, vp]
     L.sky_nms_fetch.argtypes = [vp, vp, ip, vp, vp]
     L.sky_box_iou.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp]
+    L.sky_num_packed.argtypes = [vp]
+    L.sky_packed_info.argtypes = [vp, ip, ctypes.POINTER(SkyPackedDesc)]
+    L.sky_packed_read.argtypes = [vp, ip, vp, ctypes.c_size_t, vp, ctypes.c_size_t]
     L.sky_letterbox.argtypes = [vp, vp, ip, ip, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     _lib = L
     return L
@@ -200,6 +208,23 @@ class Handle:
         ms = ctypes.c_float()
         check(self.L.sky_time_forward(self.h, len(ins), a, len(outs), b, ctypes.c_void_p(stream), iters, ctypes.byref(ms)), self.h)
         return ms.value
+
+    def packed_weights(self):
+        """-> list of dict(name, cout, kernel_size, cin, weight [rows, kpad] (uint16 bf16 bits | float32), bias [rows] float32):
+        the BatchNorm-folded, layout-converted convolution weights exactly as the kernels read them (sky_packed_*)."""
+        import numpy as np
+        out = []
+        n = self.L.sky_num_packed(self.h)
+        if n < 0:
+            check(n, self.h)
+        for i in range(n):
+            d = SkyPackedDesc()
+            check(self.L.sky_packed_info(self.h, i, ctypes.byref(d)), self.h)
+            w = np.empty((d.rows, d.kpad), np.float32 if d.dtype == SKY_F32 else np.uint16)
+            b = np.empty((d.rows,), np.float32)
+            check(self.L.sky_packed_read(self.h, i, w.ctypes.data_as(ctypes.c_void_p), w.nbytes, b.ctypes.data_as(ctypes.c_void_p), b.size), self.h)
+            out.append(dict(name=d.name.decode(), cout=d.cout, kernel_size=d.kernel_size, cin=d.cin, weight=w, bias=b))
+        return out
 
     def profile_forward(self, ins, outs, stream, iters=3, max_ops=4096):
         """-> list of (ms, flops, tag) per launch of the planned graph."""

@@ -184,6 +184,24 @@ class NativeModule(nn.Module):
         self._engines[key] = (h, self._weights_version)
         return h
 
+    def export_engine(self, path, *example_inputs):
+        """Write the engine's own weight file for the geometry of ``example_inputs`` (export.py counterpart):
+        an .npz with, per packed convolution i, ``conv{i}.weight`` [rows, kpad] (float32, or uint16 = bf16 bits),
+        ``conv{i}.bias`` [rows] float32 and a JSON ``index`` (state-dict name, cout, kernel_size, cin, dtype).  BatchNorm is
+        folded (blocks.py:39-41 ``fused_forward``), K is (ky, kx, cin).  Returns the index."""
+        import json
+        import numpy as np
+        h = self._engine([self._prepare_input(t) for t in example_inputs])
+        packed = h.packed_weights()
+        arrays, index = {}, []
+        for i, p in enumerate(packed):
+            arrays[f"conv{i}.weight"], arrays[f"conv{i}.bias"] = p["weight"], p["bias"]
+            index.append(dict(i=i, name=p["name"], cout=p["cout"], kernel_size=p["kernel_size"], cin=p["cin"],
+                              dtype="float32" if p["weight"].dtype == np.float32 else "bfloat16"))
+        arrays["index"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
+        np.savez(path, **arrays)
+        return index
+
     def _prepare_input(self, t):
         if not torch.is_tensor(t):
             raise TypeError("SkyEye modules take torch tensors")
