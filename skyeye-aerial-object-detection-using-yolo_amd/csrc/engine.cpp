@@ -1078,6 +1078,8 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     int op_index = 0;
     if (marks) SKY_HIP(hipEventRecord(marks[0], s));
     bool took_next = false;     // the previous op's kernel also computed this (fused_prev) op
+    const void* raw_src = nullptr;   // set by a skipped FocusBlock import: the next convolution reads the caller's frames
+    int raw_mode = 0;
     for (size_t oi = 0; oi < e.ops.size(); ++oi) {
         Op& op = e.ops[oi];
         if (op.fused_prev && took_next) {
@@ -1091,6 +1093,26 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
         switch (op.kind) {
             case OP_IMPORT: {
                 const sky_buffer& src = ins[op.in.ext];
+                // FocusBlock: when the convolution that follows runs on the kernel that reads the raw frames itself
+                // (space-to-depth, /255 and conversion in its halo loader) the import is skipped
+                if (op.s2d && op.src_c == 3 && src.layout != SKY_NHWC && !op.force_nhwc && oi + 1 < e.ops.size()) {
+                    Op& nx = e.ops[oi + 1];
+                    if (nx.kind == OP_CONV && nx.in.buf == op.out.buf && nx.in.off == op.out.off && nx.ks == 3 && nx.stride == 1 && !nx.res.valid()) {
+                        ConvArgs t;
+                        memset(&t, 0, sizeof(t));
+                        t.B = nx.in.B; t.H = nx.in.H; t.W = nx.in.W; t.Cin = nx.cin; t.ldi = nx.in.ld; t.Ho = nx.Ho; t.Wo = nx.Wo; t.Cout = nx.cout;
+                        t.ldo = nx.out.ld; t.ks = 3; t.stride = 1; t.pad = 1; t.Kpad = e.convs[nx.wid].Kpad; t.up2 = nx.up2; t.head = nx.head;
+                        t.M = nx.in.B * nx.Ho * nx.Wo;
+                        const double oext = (((double)t.M - 1.0) * nx.out.ld + nx.cout) * e.esize();
+                        t.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
+                        if (conv_accepts_raw(e.dtype, t)) {
+                            raw_src = src.data;
+                            raw_mode = src.dtype == SKY_IO_U8 ? 1 : 2;
+                            op.variant = 9100;
+                            break;
+                        }
+                    }
+                }
                 SKY_HIP(launch_import(e.dtype, src.data, src.dtype == SKY_IO_U8, op.force_nhwc || src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                       op.out.B, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld, op.s2d, src.dtype == SKY_IO_U8, s));
                 break;
@@ -1104,6 +1126,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 memset(&a, 0, sizeof(a));
                 const DevConv& d = e.convs[op.wid];
                 a.in = tv_ptr(e, op.in, ins, n_in, outs, n_out);
+                if (raw_src) { a.in = raw_src; a.src_mode = raw_mode; raw_src = nullptr; }
                 a.w = d.w; a.bias = d.bias; a.Kpad = d.Kpad; a.zero = e.zero_page;
                 a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.Cin = op.cin; a.ldi = op.in.ld;
                 a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.cout;

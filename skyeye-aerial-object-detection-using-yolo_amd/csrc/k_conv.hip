@@ -417,6 +417,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant
         const hipError_t e = launch_conv_stream(dtype, a, s, variant, fused);
         if (e != hipErrorNotSupported) return e;
     }
+    if (a.src_mode) return hipErrorNotSupported;      // only the narrow-input halo kernel reads raw frames (engine checks conv_accepts_raw)
     if (variant) *variant = 1000 + conv_pick_bn(a.Cout);
     return dtype == 0 ? launch_t<float>(a, s) : launch_t<__bf16>(a, s);
 }

@@ -408,7 +408,11 @@ __global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a
 static constexpr int SPX = 384;               // pixel slots per plane (324 used): 6 DMA instructions of 64 pixels
 static constexpr int SPL = SPX * 16;          // bytes per plane = 24 * 256
 
-template <typename T, int CB, int NF, bool SQ>
+// SRC: 0 = the input is an NHWC tensor of T (LDS-DMA); 1 / 2 = the input is the caller's raw [B, 3, 2H, 2W] frame batch
+// (uint8 / float32, NCHW) and FocusBlock's space-to-depth (blocks.py:176-181: patches TL, BL, TR, BR -> channel patch*3 + c),
+// the /255 of the uint8 contract (validate.py:238, true division) and the conversion to T happen while the halo tile is
+// built: the stem reads 4.9 MB per frame instead of the 13 MB intermediate an import kernel would write and it read back.
+template <typename T, int CB, int NF, bool SQ, int SRC = 0>
 __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
@@ -419,10 +423,18 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     constexpr int NKS = (KBYTES + 63) / 64;       // 64-byte K-steps
     constexpr int WBUF = NB * 256;                // one slab of weights
     constexpr int NPIECE = NPL * 6 / HWV;         // halo DMA instructions per wave per tile
+    constexpr int RAWP = 40;                      // bytes per staged raw row: 2 * 18 halo columns + 4 (16 x 16 tiles only)
+    constexpr int RAW_ROWS = 3 * 36;              // colours x raw rows of the 18-row halo
+    constexpr int RAW_BYTES = SRC == 1 ? RAW_ROWS * RAWP : 0;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const wlds = smem;
     char* const hlds = smem + NSLAB * WBUF;
     float* const lbias = reinterpret_cast<float*>(smem + NSLAB * WBUF + 2 * HB);
+    // SRC == 1 (uint8 frames, 16 x 16 tiles): the raw bytes of a tile (3 colours x 36 rows x 40 bytes, rows starting 2 pixels
+    // left of the halo so that they are 4-byte aligned) are staged in LDS by dword loads, then turned into the channel planes through a
+    // 256-entry table of (T)(i / 255.0f) -- the exact values the import kernel would have written
+    unsigned char* const rawl = reinterpret_cast<unsigned char*>(lbias + NB);
+    T* const lut = reinterpret_cast<T*>(rawl + RAW_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -447,6 +459,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
             *reinterpret_cast<u32x4_t*>(wlds + ss * WBUF + row * 256 + ((c ^ swz) << 4)) = v;
         }
         for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
+        if (SRC == 1) lut[tid] = (T)((float)tid / 255.0f);          // 256 threads = 256 byte values
     }
 
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
@@ -483,7 +496,106 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         y0 = (q - bimg * tiles_y) * tile_h;
         x0 = tx * tile_w;
     };
+    // raw-frame source: item = (halo pixel p, 16-byte chunk c of its 16 channels); thread t owns items t, t + 256, ...
+    constexpr int EPC = 16 / (int)sizeof(T);       // channels per chunk
+    constexpr int NITEM = (NPL * SPX + HWV * 64 - 1) / (HWV * 64);
+    // SRC == 2 (float frames, the reference's own input contract): element-wise loads, kept simple (not the bench path)
+    float rawv[SRC == 2 ? NITEM : 1][SRC == 2 ? EPC : 1];
+    // SRC == 1: dword d of the tile's raw block = (row r = colour * rrows + ry, dword cd of the row)
+    const int rrows = 2 * (tile_h + 2), rdw = (2 * (tile_w + 2) + 4) / 4;     // raw rows per colour, dwords per row
+    constexpr int NDW = (RAW_ROWS * (RAWP / 4) + HWV * 64 - 1) / (HWV * 64);   // upper bound of dwords per thread
+    unsigned int rawd[SRC == 1 ? NDW : 1];
+    auto load_raw = [&](int t) {
+        int bimg, y0, x0;
+        decode_tile(t, bimg, y0, x0);
+        const int Hr = 2 * a.H, Wr = 2 * a.W;
+        if (SRC == 1) {
+            const int ntot = 3 * rrows * rdw;
+            const int ry0 = 2 * (y0 - 1), rx0 = 2 * (x0 - 1) - 2;            // rx0 is a multiple of 4 (tile_w even)
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                const int d = tid + k * (HWV * 64);
+                unsigned int v = 0u;
+                if (d < ntot) {
+                    const int r = d / rdw, cd = d - r * rdw;
+                    const int col = r / rrows, ry = r - col * rrows;
+                    const int y = ry0 + ry, x = rx0 + 4 * cd;
+                    if ((unsigned)y < (unsigned)Hr && x >= 0 && x + 3 < Wr)
+                        v = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const unsigned char*>(a.in) + (((long)bimg * 3 + col) * Hr + y) * Wr + x);
+                }
+                rawd[k] = v;
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            const int item = tid + k * (HWV * 64);
+            const int c = item / SPX, p = item - c * SPX;
+            const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;
+            const int sy = y0 - 1 + hy, sx = x0 - 1 + hx;
+            const bool ok = c < NPL && p < hpix && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int ch = c * EPC + e;           // channel of the space-to-depth map: patch * 3 + colour
+                const int patch = ch / 3, col = ch - patch * 3;
+                float v = 0.0f;
+                if (ok && ch < 12) v = reinterpret_cast<const float*>(a.in)[(((long)bimg * 3 + col) * Hr + 2 * sy + (patch & 1)) * Wr + 2 * sx + (patch >> 1)];
+                rawv[SRC == 2 ? k : 0][SRC == 2 ? e : 0] = v;
+            }
+        }
+    };
+    auto store_raw = [&](int buf) {                 // registers -> LDS planes of halo buffer `buf`
+        if (SRC == 1) {
+            const int ntot = 3 * rrows * rdw;
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                const int d = tid + k * (HWV * 64);
+                if (d < ntot) {
+                    const int r = d / rdw, cd = d - r * rdw;
+                    *reinterpret_cast<unsigned int*>(rawl + r * RAWP + cd * 4) = rawd[k];
+                }
+            }
+            __syncthreads();                        // the raw block is complete
+#pragma unroll
+            for (int k = 0; k < NITEM; ++k) {
+                const int item = tid + k * (HWV * 64);
+                const int c = item / SPX, p = item - c * SPX;
+                if (c < NPL && p < hpix) {
+                    const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;
+                    T vals[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const int ch = c * EPC + e;
+                        const int patch = ch / 3, col = ch - patch * 3;
+                        vals[e] = ch < 12 ? lut[rawl[(col * rrows + 2 * hy + (patch & 1)) * RAWP + 2 * hx + (patch >> 1) + 2]] : (T)0.0f;
+                    }
+                    *reinterpret_cast<u32x4_t*>(hlds + buf * HB + c * SPL + p * 16) = *reinterpret_cast<const u32x4_t*>(vals);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            const int item = tid + k * (HWV * 64);
+            const int c = item / SPX, p = item - c * SPX;
+            if (c < NPL) {
+                u32x4_t o;
+                if (sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 lo = (__bf16)rawv[SRC == 2 ? k : 0][SRC == 2 ? (2 * e) % EPC : 0], hi = (__bf16)rawv[SRC == 2 ? k : 0][SRC == 2 ? (2 * e + 1) % EPC : 0];
+                        o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(rawv[SRC == 2 ? k : 0][SRC == 2 ? e % EPC : 0]);
+                }
+                *reinterpret_cast<u32x4_t*>(hlds + buf * HB + c * SPL + p * 16) = o;
+            }
+        }
+    };
     auto issue_halo = [&](int t, int buf) {
+        if (SRC) { load_raw(t); return; }
         int bimg, y0, x0;
         decode_tile(t, bimg, y0, x0);
         const int base = ((bimg * a.H + (y0 - 1)) * a.W + (x0 - 1)) * pix_b;
@@ -505,12 +617,13 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     issue_halo(tile, 0);
+    if (SRC) store_raw(0);
     int it = 0;
     for (;;) {
         wait_vmcnt0();                 // this wave's halo pieces have landed (and the previous tile's stores)
         __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer
         const int next = tile + gridDim.x;
-        if (next < ntile) issue_halo(next, (it + 1) & 1);
+        if (next < ntile) issue_halo(next, (it + 1) & 1);      // SRC: the raw loads fly under the MFMAs; converted below
         const char* hb = hlds + (it & 1) * HB;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -531,6 +644,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         if (next >= ntile) break;
+        if (SRC) store_raw((it + 1) & 1);    // the other buffer: nobody reads it before the barrier at the loop top
         tile = next;
         ++it;
     }
@@ -608,12 +722,12 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     return hipGetLastError();
 }
 
-template <typename T, int CB, int NF, bool SQ>
+template <typename T, int CB, int NF, bool SQ, int SRC = 0>
 static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, NSLAB = (9 * CB + 255) / 256;
-    const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + NB * 4;
-    auto kern = conv_halo_small_kernel<T, CB, NF, SQ>;
+    const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + NB * 4 + (SRC == 1 ? 3 * 36 * 40 + 256 * sizeof(T) : 0);
+    auto kern = conv_halo_small_kernel<T, CB, NF, SQ, SRC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -631,12 +745,45 @@ template <typename T>
 static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStream_t s, int n_cu)
 {
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
+    if (a.src_mode) {   // raw frames (FocusBlock import fused): 16 channels = 32 B (bf16) / 64 B (fp32); source element type by mode
+        constexpr int CBR = 16 * (int)sizeof(T);
+        if (cb != CBR) return hipErrorNotSupported;
+#define SKY_RAW(NFF, SQQ) (a.src_mode == 1 ? halo_small_launch<T, CBR, NFF, SQQ, 1>(a, s, n_cu) : halo_small_launch<T, CBR, NFF, SQQ, 2>(a, s, n_cu))
+        if (nb == 32) return sq ? SKY_RAW(2, true) : SKY_RAW(2, false);
+        return sq ? SKY_RAW(4, true) : SKY_RAW(4, false);
+#undef SKY_RAW
+    }
     if (cb == 32) {
         if (nb == 32) return sq ? halo_small_launch<T, 32, 2, true>(a, s, n_cu) : halo_small_launch<T, 32, 2, false>(a, s, n_cu);
         return sq ? halo_small_launch<T, 32, 4, true>(a, s, n_cu) : halo_small_launch<T, 32, 4, false>(a, s, n_cu);
     }
     if (nb == 32) return sq ? halo_small_launch<T, 64, 2, true>(a, s, n_cu) : halo_small_launch<T, 64, 2, false>(a, s, n_cu);
     return sq ? halo_small_launch<T, 64, 4, true>(a, s, n_cu) : halo_small_launch<T, 64, 4, false>(a, s, n_cu);
+}
+
+// the checks that route a convolution to the narrow-input kernel (the only one with a raw-frame loader)
+static bool halo_small_ok(int dtype, ConvArgs& a)
+{
+    const int esz = dtype == 0 ? 4 : 2;
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2) return false;
+    if ((!a.src_mode && a.in_bytes == 0) || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return false;
+    const long cb = (long)a.Cin * esz;
+    if (!((cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0))) return false;
+    if ((long)a.Kpad * esz < 9L * a.Cin * esz || (long)a.Cout * a.Kpad * esz >= (1L << 31)) return false;
+    const char* mode = getenv("SKY_CONV_HALO");
+    if (mode && mode[0] == '0') return false;
+    const double cover = pick_tile(a, SPX);
+    return (mode && mode[0] == 'f') || cover >= 0.75;
+}
+
+bool conv_accepts_raw(int dtype, const ConvArgs& a0)
+{
+    static const bool off = getenv("SKY_NO_FUSED_IMPORT") != nullptr;       // A/B switch
+    if (off) return false;
+    ConvArgs a = a0;
+    a.src_mode = 1;
+    // the raw loader stages 16 x 16 tiles; dword loads want an even map width (raw width a multiple of 4)
+    return a.Cin == 16 && !a.res && halo_small_ok(dtype, a) && a.tile_w == 16 && a.tile_h == 16 && a.W % 2 == 0;
 }
 
 // returns hipErrorNotSupported when the shape is not covered / not worth it (caller falls back to the streaming kernel)
@@ -652,10 +799,10 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     }
     const int esz = dtype == 0 ? 4 : 2;
     if (a.ks != 3 || (a.stride != 1 && a.stride != 2) || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
-    if (a.in_bytes == 0 || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
+    if ((!a.src_mode && a.in_bytes == 0) || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
     const long cb = (long)a.Cin * esz;
     const bool small = a.stride == 1 && (cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0);
-    if (!small && (cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
+    if (!small && (a.src_mode || cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
     const char* mode = getenv("SKY_CONV_HALO");   // "0": never, "force": whenever the shape is covered

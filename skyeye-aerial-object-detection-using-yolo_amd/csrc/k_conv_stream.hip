@@ -543,6 +543,7 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if (a.src_mode) return hipErrorNotSupported;
     const StreamPlan p = stream_plan(dtype, a);
     if (p.nf == 0) return hipErrorNotSupported;
     const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu, fused) : stream_dispatch_t<__bf16>(p, a, s, n_cu, fused);

@@ -34,6 +34,9 @@ struct ConvArgs {
     int tile_w, tile_h;         // halo-tile kernels: output tile shape (tile_w * tile_h <= 256)
     unsigned magic_w, magic_h;  // halo-tile kernels: 2^16 / tile_w + 1, 2^16 / (tile_w + 2) + 1 (exact division of small indices)
     int dbg;             // kernel experiments (SKY_CONV_DBG), 0 in production
+    int src_mode;        // 0: `in` is an NHWC tensor of T.  1 / 2: `in` is the caller's raw [B, 3, 2H, 2W] uint8 / float32 NCHW
+                         // frame batch and FocusBlock's space-to-depth + /255 + conversion are fused into the convolution's
+                         // loader (narrow-input halo kernel only; conv_accepts_raw() tells whether a launch would take it)
     // optional second, fused 1x1 convolution (back-to-back GEMM in the epilogue): out2 = act2(W2 * out[:, koff:koff+cin2] + b2)
     // where `out` is this convolution's own (packed) output; honoured only by kernels that hold all Cout channels of a
     // pixel in one workgroup -- the launcher reports through *fused whether it was
@@ -67,6 +70,8 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 // variant 4000 + N_blk; hipErrorNotSupported when the shape is not covered.  SKY_CONV_HALO=0 disables, =force ignores
 // the tile-fill heuristic.
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr, int* fused = nullptr);
+// would launch_conv run this (3x3, stride 1, 16-channel) convolution on the kernel that reads raw frames (ConvArgs::src_mode)?
+bool conv_accepts_raw(int dtype, const ConvArgs& a);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
