@@ -16,8 +16,8 @@
  *   - device pointers are plain HIP device pointers (e.g. torch.Tensor.data_ptr()); `stream` is a
  *     hipStream_t passed as void* (NULL = the null stream)
  *   - one handle per (device, stream); a handle is not thread-safe, different handles are independent
- *   - all kernels are launched asynchronously on `stream`; the only host synchronisation is inside
- *     sky_nms_fetch (it returns counts to the host)
+ *   - all kernels are launched asynchronously on `stream`; host synchronisation happens only inside
+ *     sky_nms_fetch (it returns counts to the host), sky_packed_read (weights to the host) and the timing hooks
  */
 #ifndef SKYEYE_HIP_H
 #define SKYEYE_HIP_H
