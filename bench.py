@@ -141,7 +141,7 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-        "p50_latency_ms": round(lat[len(lat) // 2], 3),
+        "p50_latency_ms": round(lat[len(lat) // 2], 3), "p99_latency_ms": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 3),
         "config": {"workload": f"{a.model} {a.precision} batch={B}/GPU @{S}x{S}: uint8 frames in HBM -> backbone+neck+heads+"
                                f"decode -> NMS(conf {a.conf}, iou {a.iou}, max_det 300)"
                                + (" -> RCCL all-gather of boxes" if world > 1 else ""),
