@@ -692,7 +692,10 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
         fprintf(stderr, "conv_halo<NF=%d>: %d workgroups per CU with %zu B of LDS\n", NF, nb, lds);
     }
     const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
-    int gx = ntile < 2 * n_cu ? ntile : 2 * n_cu;
+    // two workgroups per CU in total: with several N tiles the tile range is split over fewer, longer-lived workgroups
+    const int gy = a.Cout / NB;
+    const int slots = getenv("SKY_STREAM_OLDGRID") ? 2 * n_cu : (2 * n_cu / gy > 0 ? 2 * n_cu / gy : 1);
+    int gx = ntile < slots ? ntile : slots;
     if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
     static unsigned long long* stamps = nullptr;
     if (a.dbg & 256) {
@@ -736,7 +739,9 @@ static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
     }
     const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;
     const int ntile = a.B * ((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w);
-    const int gx = ntile < per_cu * n_cu ? ntile : per_cu * n_cu;
+    const int gy = a.Cout / NB;
+    const int slots = per_cu * n_cu / gy > 0 ? per_cu * n_cu / gy : 1;
+    const int gx = ntile < slots ? ntile : slots;
     kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
     return hipGetLastError();
 }

@@ -455,7 +455,12 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     }
     const int ntiles = (a.M + TPX - 1) / TPX;
     int gx = (ntiles + SW - 1) / SW;
-    if (gx > n_cu) gx = n_cu;
+    // one workgroup per CU in total (the kernel's registers / LDS allow no second one): with several N tiles the pixel
+    // range is split over n_cu / gy persistent workgroups each, instead of gy rounds of short-lived ones that would each
+    // pay the prologue (bias, first weight slab, first pixel slab) again
+    const int gy = a.Cout / NB;
+    const int cap = getenv("SKY_STREAM_OLDGRID") ? n_cu : (n_cu / gy > 0 ? n_cu / gy : 1);
+    if (gx > cap) gx = cap;
     hipLaunchKernelGGL(kern, dim3(gx, a.Cout / NB), dim3(SW * 64), lds, s, a);
     return hipGetLastError();
 }
