@@ -650,6 +650,126 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     }
 }
 
+// ---- narrow inputs, stride 2 (64 bytes of channels per pixel: the 32 -> 64 convolution after the stem) ----
+// The stride-2 scheme of conv_halo_kernel on the narrow kernel's machinery: the four parity phases of the input are
+// staged one after the other as unit-stride cell tiles into the two halo buffers in turn (phase p + 1 is fetched while the
+// 4 / 2 / 2 / 1 taps of phase p compute), all of K resident in LDS, one barrier per phase, epilogue after the fourth.
+template <typename T, int NF, bool SQ>
+__global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const ConvArgs a)
+{
+    constexpr int NB = NF * 16, NPL = 4, HB = NPL * SPL, NSLAB = 3, WBUF = NB * 256, NPIECE = NPL * 6 / HWV;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const wlds = smem;
+    char* const hlds = smem + NSLAB * WBUF;
+    float* const lbias = reinterpret_cast<float*>(smem + NSLAB * WBUF + 2 * HB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.y * NB;
+    const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
+    const int tiles_x = (a.Wo + tile_w - 1) / tile_w, tiles_y = (a.Ho + tile_h - 1) / tile_h;
+    const int hpw = tile_w + 2, hpix = hpw * (tile_h + 2);
+    const int ntile = a.B * tiles_y * tiles_x;
+    const int pix_b = a.ldi * (int)sizeof(T);
+    int tile = blockIdx.x;
+    if (tile >= ntile) return;
+    {
+        const char* wsrc = reinterpret_cast<const char*>(a.w);
+        const long wpitch = (long)a.Kpad * (long)sizeof(T);
+        for (int idx = tid; idx < NSLAB * NB * 16; idx += HWV * 64) {
+            const int ss = idx / (NB * 16), rc = idx - ss * (NB * 16);
+            const int row = rc >> 4, c = rc & 15;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(wsrc + (long)(n0 + row) * wpitch + ss * 256 + c * 16);
+            const int swz = (row & 3) | (((row >> 3) & 3) << 2);
+            *reinterpret_cast<u32x4_t*>(wlds + ss * WBUF + row * 256 + ((c ^ swz) << 4)) = v;
+        }
+        for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
+    }
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
+    int pbi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ty, tx;
+        tile_pixel<SQ>(a, wave * 64 + i * 16 + fr, ty, tx);
+        pbi[i] = fq * SPL + (ty < 0 ? 0 : ty * hpw + tx) * 16;      // K-group fq = 16-byte chunk fq of the pixel's 64 bytes
+    }
+    const int wrow0 = (fr >> 2) * 8 + (fr & 3);
+    const int wsw0 = (wrow0 & 3) | (((wrow0 >> 3) & 3) << 2);
+    const char* const wfrag = wlds + wrow0 * 256;
+    auto decode_tile = [&](int t, int& bimg, int& y0, int& x0) {
+        const int tx = t % tiles_x;
+        const int q = t / tiles_x;
+        bimg = q / tiles_y;
+        y0 = (q - bimg * tiles_y) * tile_h;
+        x0 = tx * tile_w;
+    };
+    // phase ph (order of tap_step<true>: odd/odd, odd rows/even cols, even rows/odd cols, even/even) of tile t
+    auto issue_halo = [&](int t, int ph, int buf) {
+        int bimg, y0, x0;
+        decode_tile(t, bimg, y0, x0);
+        const int dy = ph < 2, dx = (ph & 1) == 0;
+        const int ry0 = 2 * (y0 - 1) + dy, rx0 = 2 * (x0 - 1) + dx;
+        const int base = ((bimg * a.H + ry0) * a.W + rx0) * pix_b;
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            const int q = wave + HWV * j;
+            const int c = q / 6, b = q - c * 6;
+            const int p = b * 64 + lane;
+            const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;
+            const bool ok = p < hpix && (unsigned)(ry0 + 2 * hy) < (unsigned)a.H && (unsigned)(rx0 + 2 * hx) < (unsigned)a.W;
+            lds_dma16(irsrc, hlds + buf * HB + c * SPL + b * 1024, ok ? base + (2 * hy * a.W + 2 * hx) * pix_b + c * 16 : -1, 0);
+        }
+    };
+    f32x4_t acc[NF][4];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    issue_halo(tile, 0, 0);
+    int u = 0;                                    // (tile, phase) counter: halo buffer u & 1
+    for (;;) {
+        const int next = tile + gridDim.x;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            wait_vmcnt0();
+            __syncthreads();
+            if (ph < 3) issue_halo(tile, ph + 1, (u + 1) & 1);
+            else if (next < ntile) issue_halo(next, 0, (u + 1) & 1);
+            const char* hb = hlds + (u & 1) * HB;
+            constexpr int Q0[4] = {0, 4, 6, 8}, QN[4] = {4, 2, 2, 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < QN[ph]) {
+                    const int tap = tap_step<true>(Q0[ph] + k).tap;           // compile-time after unrolling
+                    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                    const int toff = ((ky != 0) * hpw + (kx != 0)) * 16;
+                    u32x4_t pf[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const u32x4_t*>(hb + (SQ ? pbi[0] + i * (18 * 16) : pbi[i]) + toff);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wfrag + (tap >> 2) * WBUF + ((j >> 1) * 32 + (j & 1) * 4) * 256 +
+                                                                              ((((tap & 3) * 4 + fq) ^ wsw0) << 4));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) S1<T>::mma(wf, pf[i], acc[j][i]);
+                    }
+                }
+            }
+            ++u;
+        }
+        int bimg, y0, x0;
+        decode_tile(tile, bimg, y0, x0);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        if (next >= ntile) break;
+        tile = next;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 // Tile shape: th x tw <= 256 output pixels whose (th+2) x (tw+2) halo fits `slots` pixel slots, chosen to waste the
 // least matrix work on this image size (16 x 16 when the sides divide; a 40-wide map gets 6 x 40).  Widths that are
@@ -746,6 +866,27 @@ static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
     return hipGetLastError();
 }
 
+template <typename T, int NF, bool SQ>
+static hipError_t halo_small_s2_launch(const ConvArgs& a, hipStream_t s, int n_cu)
+{
+    constexpr int NB = NF * 16;
+    const size_t lds = (size_t)3 * NB * 256 + 2 * 4 * SPL + NB * 4;
+    auto kern = conv_halo_small_s2_kernel<T, NF, SQ>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;
+    const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
+    const int gy = a.Cout / NB;
+    const int slots = per_cu * n_cu / gy > 0 ? per_cu * n_cu / gy : 1;
+    const int gx = ntile < slots ? ntile : slots;
+    kern<<<dim3(gx, gy), dim3(HWV * 64), lds, s>>>(a);
+    return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStream_t s, int n_cu)
 {
@@ -807,6 +948,26 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     if ((!a.src_mode && a.in_bytes == 0) || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
     const long cb = (long)a.Cin * esz;
     const bool small = a.stride == 1 && (cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0);
+    const bool small_s2 = a.stride == 2 && cb == 64 && (a.Cout == 32 || a.Cout % 64 == 0) && !a.src_mode && !a.f2_w;
+    if (small_s2) {
+        if ((long)a.Kpad * esz < 9L * a.Cin * esz || (long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
+        // measured slower than the streaming kernel on its one layer of skyeye_s (32 -> 64 @640 -> 320: 0.385 vs 0.336 ms, the
+        // layer is HBM-bound and four DMA phases per tile cost more than they save): only used when forced (tests)
+        const char* md = getenv("SKY_CONV_HALO");
+        if (!(md && md[0] == 'f')) return hipErrorNotSupported;
+        pick_tile(a, SPX);
+        const bool sq2 = a.tile_w == 16 && a.tile_h == 16;
+        hipError_t e2;
+        if (a.Cout == 32) {
+            if (dtype == 0) e2 = sq2 ? halo_small_s2_launch<float, 2, true>(a, s, n_cu) : halo_small_s2_launch<float, 2, false>(a, s, n_cu);
+            else e2 = sq2 ? halo_small_s2_launch<__bf16, 2, true>(a, s, n_cu) : halo_small_s2_launch<__bf16, 2, false>(a, s, n_cu);
+        } else {
+            if (dtype == 0) e2 = sq2 ? halo_small_s2_launch<float, 4, true>(a, s, n_cu) : halo_small_s2_launch<float, 4, false>(a, s, n_cu);
+            else e2 = sq2 ? halo_small_s2_launch<__bf16, 4, true>(a, s, n_cu) : halo_small_s2_launch<__bf16, 4, false>(a, s, n_cu);
+        }
+        if (e2 == hipSuccess && variant) *variant = 6000 + (a.Cout == 32 ? 32 : 64);
+        return e2;
+    }
     if (!small && (a.src_mode || cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;

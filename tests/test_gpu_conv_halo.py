@@ -88,6 +88,11 @@ S2_CASES = [
     (128, 128, 2, 40, 40),    # 20 x 20 outputs
     (256, 64, 1, 16, 16),     # four chunks, N_blk 64
     (64, 64, 3, 64, 64),      # several tiles per workgroup
+    # narrow stride-2 kernel (64 bytes of channels per pixel: 32 bf16 / 16 fp32 channels)
+    (32, 64, 2, 64, 64),
+    (32, 32, 1, 33, 41),
+    (16, 64, 2, 32, 48),
+    (32, 64, 5, 96, 96),
 ]
 
 
