@@ -1221,7 +1221,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 float awh[16];
                 for (int k = 0; k < cf.num_anchors * 2; ++k) awh[k] = cf.anchors[op.level * cf.num_anchors * 2 + k] * op.stride_px;
                 TV dt; dt.ext = op.det_ext;
-                SKY_HIP(launch_decode((const float*)ins[op.in.ext].data, (float*)tv_ptr(e, dt, ins, n_in, outs, n_out), op.in.B, cf.num_anchors,
+                SKY_HIP(launch_decode(e.dtype, (const float*)ins[op.in.ext].data, (float*)tv_ptr(e, dt, ins, n_in, outs, n_out), op.in.B, cf.num_anchors,
                                       op.Ho, op.Wo, cf.nc + 5, op.det_rows, op.det_off, op.stride_px, awh, s));
                 break;
             }

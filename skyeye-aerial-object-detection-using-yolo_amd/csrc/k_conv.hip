@@ -241,24 +241,68 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         __syncthreads();
         const int per = BM * a.no;
         const unsigned magic = (unsigned)(0x100000000ull / (unsigned)a.no) + 1u;    // r / no == umulhi(r, magic) for r < 2^16
-        for (int an = 0; an < a.na; ++an) {
+        // one element: raw logit + decoded value of (pixel ml, output o) of anchor `an`
+        auto element = [&](int an, int ml, int o, float aw, float ah, float& rawv, float& detv) {
 #pragma clang fp contract(off)
+            const int n = an * a.no + o;
+            const float v = ot[ml * OP + n] + a.bias[n];
+            rawv = v;
+            const float s = head_sigmoid<sizeof(T) == 2>(v);
+            float d;
+            if (o == 0) d = (s * 2.0f - 0.5f + gx[ml]) * a.stride_px;
+            else if (o == 1) d = (s * 2.0f - 0.5f + gx[BM + ml]) * a.stride_px;
+            else if (o == 2 || o == 3) { const float t2 = s * 2.0f; d = (t2 * t2) * (o == 2 ? aw : ah); }
+            else d = s;
+            detv = d;
+        };
+        // 16-byte stores when the runs are 16-byte aligned: (tile start, image size, det offset) * no all multiples of 4 floats
+        const bool vec = (per & 3) == 0 && (((long)m0 * a.no) & 3) == 0 && (((long)HoWo * a.no) & 3) == 0 &&
+                         (((long)a.det_off * a.no) & 3) == 0 && (((long)a.det_rows * a.no) & 3) == 0 &&
+                         ((reinterpret_cast<size_t>(a.raw) | reinterpret_cast<size_t>(a.det)) & 15) == 0;
+        for (int an = 0; an < a.na; ++an) {
             const float aw = a.anchor_wh[an * 2], ah = a.anchor_wh[an * 2 + 1];
+            if (vec) {
+                for (int r4 = tid; r4 < per / 4; r4 += NT) {
+                    const int r0 = r4 * 4;
+                    const int ml0 = (int)__umulhi((unsigned)r0, magic), ml3 = (int)__umulhi((unsigned)(r0 + 3), magic);
+                    const int c0 = rowb[ml0], c3 = rowb[ml3];
+                    if (c0 >= 0 && c3 >= 0 && c3 - c0 == ml3 - ml0) {      // the 4 elements are contiguous in raw and in det
+                        f32x4_t rv4, dv4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = r0 + e;
+                            const int ml = (int)__umulhi((unsigned)r, magic);
+                            float rv, dv;
+                            element(an, ml, r - ml * a.no, aw, ah, rv, dv);
+                            rv4[e] = rv;
+                            dv4[e] = dv;
+                        }
+                        const int o0 = r0 - ml0 * a.no;
+                        *reinterpret_cast<f32x4_t*>(a.raw + (long)(c0 + an * HoWo) * a.no + o0) = rv4;
+                        *reinterpret_cast<f32x4_t*>(a.det + (long)(rowb[BM + ml0] + an * HoWo) * a.no + o0) = dv4;
+                    } else {
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = r0 + e;
+                            const int ml = (int)__umulhi((unsigned)r, magic);
+                            const int o = r - ml * a.no;
+                            if (rowb[ml] < 0) continue;
+                            float rv, dv;
+                            element(an, ml, o, aw, ah, rv, dv);
+                            a.raw[(long)(rowb[ml] + an * HoWo) * a.no + o] = rv;
+                            a.det[(long)(rowb[BM + ml] + an * HoWo) * a.no + o] = dv;
+                        }
+                    }
+                }
+                continue;
+            }
             for (int r = tid; r < per; r += NT) {
                 const int ml = (int)__umulhi((unsigned)r, magic);
                 const int o = r - ml * a.no;
-                const int cell = rowb[ml];
-                if (cell < 0) continue;
-                const int n = an * a.no + o;
-                const float v = ot[ml * OP + n] + a.bias[n];
-                a.raw[(long)(cell + an * HoWo) * a.no + o] = v;
-                const float s = 1.0f / (1.0f + expf(-v));
-                float d;
-                if (o == 0) d = (s * 2.0f - 0.5f + gx[ml]) * a.stride_px;
-                else if (o == 1) d = (s * 2.0f - 0.5f + gx[BM + ml]) * a.stride_px;
-                else if (o == 2 || o == 3) { const float t2 = s * 2.0f; d = (t2 * t2) * (o == 2 ? aw : ah); }
-                else d = s;
-                a.det[(long)(rowb[BM + ml] + an * HoWo) * a.no + o] = d;
+                if (rowb[ml] < 0) continue;
+                float rv, dv;
+                element(an, ml, o, aw, ah, rv, dv);
+                a.raw[(long)(rowb[ml] + an * HoWo) * a.no + o] = rv;
+                a.det[(long)(rowb[BM + ml] + an * HoWo) * a.no + o] = dv;
             }
         }
         return;
@@ -278,7 +322,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             const int b = t / a.Ho;
             const long cell = ((long)(b * a.na + an) * a.Ho + y) * a.Wo + x;
             a.raw[cell * a.no + o] = v;
-            const float s = 1.0f / (1.0f + expf(-v));
+            const float s = head_sigmoid<sizeof(T) == 2>(v);
             float d;
             if (o == 0) d = (s * 2.0f - 0.5f + (float)x) * a.stride_px;
             else if (o == 1) d = (s * 2.0f - 0.5f + (float)y) * a.stride_px;

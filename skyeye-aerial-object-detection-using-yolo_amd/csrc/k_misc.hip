@@ -292,6 +292,7 @@ hipError_t launch_upsample(int dtype, const void* src, int lds_, void* dst, int 
 // ------------------------------------------------------------------------------------------------ decode
 struct AnchorPack { float wh[16]; };
 
+template <bool FAST>
 __global__ void decode_kernel(const float* __restrict__ raw, float* __restrict__ det, int B, int na, int gh, int gw, int no,
                               long det_rows, long det_off, float stride_px, AnchorPack an)
 {
@@ -306,7 +307,7 @@ __global__ void decode_kernel(const float* __restrict__ raw, float* __restrict__
         t /= gh;
         const int a = (int)(t % na);
         const int b = (int)(t / na);
-        const float s = 1.0f / (1.0f + expf(-raw[i]));
+        const float s = head_sigmoid<FAST>(raw[i]);
         float d;
         if (o == 0) d = (s * 2.0f - 0.5f + (float)x) * stride_px;
         else if (o == 1) d = (s * 2.0f - 0.5f + (float)y) * stride_px;
@@ -316,14 +317,16 @@ __global__ void decode_kernel(const float* __restrict__ raw, float* __restrict__
     }
 }
 
-hipError_t launch_decode(const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
+hipError_t launch_decode(int dtype, const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
                          float stride_px, const float* anchor_wh, hipStream_t s)
 {
     AnchorPack an;
     for (int i = 0; i < 16; ++i) an.wh[i] = i < na * 2 ? anchor_wh[i] : 0.0f;
     const long total = (long)B * na * gh * gw * no;
-    hipLaunchKernelGGL(decode_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, raw, det, B, na, gh, gw, no, det_rows, det_off,
-                       stride_px, an);
+    if (dtype == 0) hipLaunchKernelGGL(decode_kernel<false>, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, raw, det, B, na, gh, gw, no, det_rows,
+                                       det_off, stride_px, an);
+    else hipLaunchKernelGGL(decode_kernel<true>, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, raw, det, B, na, gh, gw, no, det_rows, det_off,
+                            stride_px, an);
     return hipGetLastError();
 }
 

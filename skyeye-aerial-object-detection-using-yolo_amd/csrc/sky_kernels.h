@@ -58,6 +58,18 @@ struct ConvArgs {
     float anchor_wh[16]; // anchors[level][a][w,h] * stride_px
 };
 
+// sigmoid of the detection decode (detector.py:131): IEEE division + expf in the exact (fp32) engine; v_exp_f32 / v_rcp_f32
+// (1 ulp each, far inside the 1e-4 decode tolerance) in the bf16 engine, where the epilogue is VALU-bound.  The fused head
+// epilogue and the standalone process_detections kernel use the same form per engine: they stay equal bit for bit.
+#if defined(__HIPCC__)
+template <bool FAST>
+__device__ __forceinline__ float head_sigmoid(float v)
+{
+    if (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+    return 1.0f / (1.0f + expf(-v));
+}
+#endif
+
 int conv_pick_bn(int cout);                      // N tile chosen for a given Cout
 size_t conv_weight_rows(int cout);               // rows the packed weight / bias must have
 int conv_k_step(int dtype);                      // elements per 128-byte K-step
@@ -93,7 +105,7 @@ hipError_t launch_letterbox(const unsigned char* src, int H0, int W0, unsigned c
                             int pad, int chw, int rev, hipStream_t s);
 
 // DetectionHead.process_detections alone (detector.py:88-145): raw [B,na,gh,gw,no] -> det rows of one level
-hipError_t launch_decode(const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
+hipError_t launch_decode(int dtype, const float* raw, float* det, int B, int na, int gh, int gw, int no, long det_rows, long det_off,
                          float stride_px, const float* anchor_wh /*host, na*2, already * stride*/, hipStream_t s);
 
 // ---- CBAM (attention.py:11-130) ----

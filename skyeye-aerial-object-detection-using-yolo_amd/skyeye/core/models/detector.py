@@ -54,7 +54,9 @@ class DetectionHead(NativeModule):
     def process_detections(self, outputs, input_shape):
         """raw levels -> [B, sum(anchors*H*W), outputs] boxes (detector.py:88-145); anchor*stride quirk (D13) kept."""
         dec = _Decode(self.num_classes, self.anchors)
-        dec.__dict__["_precision"] = "fp32"
+        # same engine as the head itself: the bf16 engine's decode uses the fast sigmoid of its fused epilogue, the exact
+        # engine the IEEE one, so that detect() and forward() + process_detections() agree bit for bit
+        dec.__dict__["_precision"] = self._resolved_precision()
         return dec._run(list(outputs), dict(input_h=int(input_shape[0]), input_w=int(input_shape[1])))[0]
 
     def detect(self, feature_maps, input_shape):
