@@ -213,6 +213,30 @@ int sky_packed_read(sky_handle* h, int i, void* weights_host, size_t weight_byte
 int sky_letterbox(sky_handle* h, const uint8_t* src, int H0, int W0, uint8_t* dst, int H1, int W1, int new_h, int new_w,
                   int top, int left, int pad_value, int dst_chw, int reverse_channels, void* stream);
 
+/* Test-time augmentation and tiling front end.  The reference plumbs `augment=` through both CLIs
+ * (validate.py:245, detect.py:140) but has no body for it; the schedule is YOLOv5's _forward_augment (scales 1 / 0.83 / 0.67, the
+ * middle pass flipped left-right), built from the reference's own scale_img.
+ *
+ * sky_scale_img: scale_img (utils/torch_utils.py:262-288) of `src.flip(flip)`: src [B, C, H, W] fp32, or uint8 (then /255 first,
+ * validate.py:236-238) -> bilinear (align_corners = False, ATen's arithmetic) to (out_h, out_w) = (int(H*ratio), int(W*ratio)) at
+ * the top-left of dst [B, C, pad_h, pad_w] fp32, the rest filled with pad_value (0.447).  flip: 0, 2 (rows) or 3 (columns).
+ * out == in copies (ratio 1.0).  The caller computes the geometry (skyeye.utils.torch_utils.scale_img does). */
+int sky_scale_img(sky_handle* h, const void* src, int src_dtype, int B, int C, int H, int W, float* dst, int out_h, int out_w, int pad_h, int pad_w,
+                  int flip, float pad_value, void* stream);
+
+/* Map decoded rows back to the frame of the original image and place them in the concatenated result: rows [row0, row0 + rows) of
+ * src [B, N, no] go to dst[b / tiles_per_image][dst_row0 + (b % tiles_per_image) * rows + r]; dst is [B / tiles_per_image, dst_rows, no].
+ * Columns 0..3 (cx, cy, w, h): `/= scale`; flip 3: cx = img_w - cx; flip 2: cy = img_h - cy (YOLOv5 _descale_pred); then, if
+ * origins != NULL (device int32 [B, 2] = (y, x) of each tile), cx += x, cy += y.  Other columns are copied. */
+int sky_map_detections(sky_handle* h, const float* src, int B, int N, int no, int row0, int rows, float scale, int flip, float img_h, float img_w,
+                       const int32_t* origins, int tiles_per_image, float* dst, int64_t dst_rows, int64_t dst_row0, void* stream);
+
+/* Large-frame tiling: src uint8 [H0, W0, 3] (src_chw = 0) or [3, H0, W0] (src_chw = 1) on the device -> dst uint8 [n, 3, tile_h, tile_w],
+ * tile t = the window at origins[t] = (y, x) (device int32 [n, 2]); pixels outside the frame = pad_value (114);
+ * reverse_channels = 1 flips BGR <-> RGB (detect.py:133).  dst is directly the engine's uint8 input. */
+int sky_tile_gather(sky_handle* h, const uint8_t* src, int H0, int W0, int src_chw, const int32_t* origins, int n, uint8_t* dst, int tile_h,
+                    int tile_w, int pad_value, int reverse_channels, void* stream);
+
 /* box_iou (metrics.py:17-44), the pairwise IoU of the evaluation accounting (validate.py:71-108 process_batch):
  * out[n, m] fp32 on the device.  box1_is_4xn = 1 reads box1 as [4, n] -- the indexing the file actually performs
  *  --, 0 as [n, 4]; box2 is [m, 4], corners (x1, y1, x2, y2).  Asynchronous on `stream`. */

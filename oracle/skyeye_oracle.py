@@ -462,3 +462,96 @@ def letterbox_pixels(img, new_h, new_w, top, bottom, left, right, pad=114):
     out = np.full((new_h + top + bottom, new_w + left + right, 3), pad, np.uint8)
     out[top:top + new_h, left:left + new_w] = res
     return out
+
+
+# --------------------------------------------------------------------------- test-time augmentation + tiling
+TTA_SCALES = (1.0, 0.83, 0.67)     # the YOLOv5 _forward_augment schedule the reference's `augment=` flag stands for
+TTA_FLIPS = (0, 3, 0)              # 3 = left-right (tensor dim 3), 2 = up-down
+
+
+def scale_img_geometry(h, w, ratio, same_shape=False, gs=32):
+    """(resized h, w), (padded h, w) of scale_img, torch_utils.py:275-288 (python float arithmetic, int() truncation)."""
+    import math
+    s = (int(h * ratio), int(w * ratio))
+    if same_shape:
+        return s, (h, w)
+    return s, tuple(math.ceil(v * ratio / gs) * gs for v in (h, w))
+
+
+def scale_img(img, ratio=1.0, same_shape=False, gs=32, flip=0):
+    """scale_img (torch_utils.py:262-288) of ``img.flip(flip)``: bilinear (align_corners=False) to int(h*ratio) x int(w*ratio),
+    zero-origin pad with 0.447 up to the next multiple of ``gs``.  ratio == 1.0 returns the (flipped) image."""
+    x = _c(img)
+    B, C, H, W = x.shape
+    if ratio == 1.0:
+        s, p = (H, W), (H, W)
+    else:
+        s, p = scale_img_geometry(H, W, ratio, same_shape, gs)
+    y = np.empty((B, C, p[0], p[1]), np.float32)
+    lib = _lib()
+    lib.sky_oracle_scale_img.argtypes = [_F, _F] + [ctypes.c_int] * 8 + [ctypes.c_float]
+    lib.sky_oracle_scale_img(_p(x), _p(y), B * C, H, W, s[0], s[1], p[0], p[1], int(flip), np.float32(0.447))
+    return y
+
+
+def map_detections(det, scale=1.0, flip=0, img_hw=(0, 0), origins=None):
+    """De-scale / un-flip / offset decoded rows [..., (cx, cy, w, h, obj, cls...)]: ``p[..., :4] /= scale``; flip 3:
+    ``cx = img_w - cx``; flip 2: ``cy = img_h - cy`` (YOLOv5 _descale_pred); tiles: ``cx += origin_x``, ``cy += origin_y``
+    (origins [B, 2] = (y, x) per batch entry).  fp32, one rounding per operation."""
+    d = np.array(det, np.float32, copy=True)
+    d[..., :4] = d[..., :4] / np.float32(scale)
+    if flip == 3:
+        d[..., 0] = np.float32(img_hw[1]) - d[..., 0]
+    elif flip == 2:
+        d[..., 1] = np.float32(img_hw[0]) - d[..., 1]
+    if origins is not None:
+        o = np.asarray(origins, np.float32)
+        d[..., 0] = d[..., 0] + o[:, 1].reshape((-1,) + (1,) * (d.ndim - 2))
+        d[..., 1] = d[..., 1] + o[:, 0].reshape((-1,) + (1,) * (d.ndim - 2))
+    return d
+
+
+def tta_rows(n_rows, n_levels=3):
+    """Row ranges kept per pass by YOLOv5's _clip_augmented: the full-scale pass drops its last (coarsest) level, the
+    smallest pass drops its first (finest) level; rows per level are in the ratio 4^(nl-1) : ... : 1."""
+    g = sum(4 ** k for k in range(n_levels))
+    return lambda k, n_pass: ((0, n_rows[k] - n_rows[k] // g) if k == 0 else
+                              ((n_rows[k] // g) * 4 ** (n_levels - 1), n_rows[k]) if k == n_pass - 1 else (0, n_rows[k]))
+
+
+def tta_forward(forward, img, gs=32, scales=TTA_SCALES, flips=TTA_FLIPS, clip=False):
+    """``forward(x) -> detections [B, N, no]`` applied to every scaled / flipped copy, rows mapped back and concatenated."""
+    H, W = img.shape[2:]
+    outs = []
+    for s, f in zip(scales, flips):
+        xi = scale_img(img, s, gs=gs, flip=f)
+        outs.append(map_detections(forward(xi), s, f, (H, W)))
+    if clip:
+        keep = tta_rows([o.shape[1] for o in outs])
+        outs = [o[:, slice(*keep(k, len(outs)))] for k, o in enumerate(outs)]
+    return np.concatenate(outs, 1)
+
+
+def tile_origins(h0, w0, tile_h, tile_w, overlap=0.2):
+    """Top-left corners (y, x) of the overlapping tiles covering an h0 x w0 frame: step = int(tile * (1 - overlap)),
+    the last tile of a row / column is pulled back flush with the border; a frame smaller than a tile gives origin 0."""
+    def axis(n, t):
+        if n <= t:
+            return [0]
+        step = max(int(t * (1.0 - overlap)), 1)
+        xs = list(range(0, n - t, step)) + [n - t]
+        return xs
+    return np.array([(y, x) for y in axis(h0, tile_h) for x in axis(w0, tile_w)], np.int32)
+
+
+def tile_gather(frame_hwc, origins, tile_h, tile_w, pad=114, reverse_channels=False):
+    """uint8 [H0, W0, 3] -> uint8 [n, 3, tile_h, tile_w]; outside the frame = ``pad``."""
+    f = np.asarray(frame_hwc, np.uint8)
+    if reverse_channels:
+        f = f[..., ::-1]
+    H0, W0 = f.shape[:2]
+    out = np.full((len(origins), 3, tile_h, tile_w), pad, np.uint8)
+    for i, (y, x) in enumerate(origins):
+        h, w = min(tile_h, H0 - y), min(tile_w, W0 - x)
+        out[i, :, :h, :w] = f[y:y + h, x:x + w].transpose(2, 0, 1)
+    return out

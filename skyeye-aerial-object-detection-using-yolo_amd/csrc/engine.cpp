@@ -1632,6 +1632,49 @@ int sky_letterbox(sky_handle* h, const uint8_t* src, int H0, int W0, uint8_t* ds
     });
 }
 
+int sky_scale_img(sky_handle* h, const void* src, int src_dtype, int B, int C, int H, int W, float* dst, int out_h, int out_w, int pad_h, int pad_w,
+                  int flip, float pad_value, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!src || !dst) throw Error(SKY_ERR_INVALID, "sky_scale_img: null argument");
+        if (src_dtype != SKY_IO_F32 && src_dtype != SKY_IO_U8) throw Error(SKY_ERR_INVALID, "sky_scale_img: source must be fp32 or uint8");
+        if (flip != 0 && flip != 2 && flip != 3) throw Error(SKY_ERR_INVALID, "sky_scale_img: flip is 0, 2 (rows) or 3 (columns)");
+        if (B < 1 || C < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1 || pad_h < out_h || pad_w < out_w)
+            throw Error(SKY_ERR_SHAPE, "sky_scale_img: the resized image must be non-empty and fit the padded destination");
+        SKY_HIP(launch_scale_img(src, src_dtype == SKY_IO_U8, B * C, H, W, dst, out_h, out_w, pad_h, pad_w, flip, pad_value, (hipStream_t)stream));
+    });
+}
+
+int sky_map_detections(sky_handle* h, const float* src, int B, int N, int no, int row0, int rows, float scale, int flip, float img_h, float img_w,
+                       const int32_t* origins, int tiles_per_image, float* dst, int64_t dst_rows, int64_t dst_row0, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!src || !dst) throw Error(SKY_ERR_INVALID, "sky_map_detections: null argument");
+        if (flip != 0 && flip != 2 && flip != 3) throw Error(SKY_ERR_INVALID, "sky_map_detections: flip is 0, 2 (rows) or 3 (columns)");
+        if (!(scale > 0.0f)) throw Error(SKY_ERR_INVALID, "sky_map_detections: scale must be positive");
+        if (B < 1 || N < 1 || no < 5 || row0 < 0 || rows < 0 || row0 + rows > N || tiles_per_image < 1 || B % tiles_per_image != 0 || dst_row0 < 0 ||
+            dst_row0 + (int64_t)tiles_per_image * rows > dst_rows)
+            throw Error(SKY_ERR_SHAPE, "sky_map_detections: source rows [row0, row0 + rows) of every tile must fit the destination image");
+        if (rows == 0) return;
+        SKY_HIP(launch_map_detections(src, B, N, no, row0, rows, scale, flip, img_h, img_w, origins, tiles_per_image, dst, (long)dst_rows,
+                                      (long)dst_row0, (hipStream_t)stream));
+    });
+}
+
+int sky_tile_gather(sky_handle* h, const uint8_t* src, int H0, int W0, int src_chw, const int32_t* origins, int n, uint8_t* dst, int tile_h,
+                    int tile_w, int pad_value, int reverse_channels, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!src || !dst || !origins) throw Error(SKY_ERR_INVALID, "sky_tile_gather: null argument");
+        if (H0 < 1 || W0 < 1 || n < 1 || tile_h < 1 || tile_w < 1) throw Error(SKY_ERR_SHAPE, "sky_tile_gather: empty frame or tile");
+        SKY_HIP(launch_tile_gather(src, H0, W0, src_chw ? 1 : 0, origins, n, dst, tile_h, tile_w, pad_value & 255, reverse_channels ? 1 : 0,
+                                   (hipStream_t)stream));
+    });
+}
+
 int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* counts_host, void* stream)
 {
     if (!h) return SKY_ERR_INVALID;

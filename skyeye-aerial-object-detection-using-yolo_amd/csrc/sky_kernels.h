@@ -158,4 +158,12 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
 // pairwise IoU [n, m] of the evaluation accounting (metrics.py:17-44); box1 [4, n] (box1_4xn) or [n, 4], box2 [m, 4]
 hipError_t launch_box_iou(const float* box1, int n, int box1_4xn, const float* box2, int m, float* out, hipStream_t s);
 
+// k_tta.hip: test-time augmentation / tiling front end
+hipError_t launch_scale_img(const void* src, int src_u8, int planes, int H, int W, float* dst, int sh, int sw, int PH, int PW, int flip, float pad,
+                            hipStream_t s);
+hipError_t launch_map_detections(const float* src, int B, int N, int no, int row0, int rows, float scale, int flip, float img_h, float img_w,
+                                 const int* origins, int tpi, float* dst, long dst_rows, long dst_row0, hipStream_t s);
+hipError_t launch_tile_gather(const unsigned char* src, int H0, int W0, int src_chw, const int* origins, int n, unsigned char* dst, int th, int tw,
+                              int pad, int rev, hipStream_t s);
+
 }  // namespace sky

@@ -55,7 +55,7 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
+           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
 _lib = None
 
@@ -109,6 +109,10 @@ def lib():
     L.sky_packed_info.argtypes = [vp, ip, ctypes.POINTER(SkyPackedDesc)]
     L.sky_packed_read.argtypes = [vp, ip, vp, ctypes.c_size_t, vp, ctypes.c_size_t]
     L.sky_letterbox.argtypes = [vp, vp, ip, ip, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    fp = ctypes.c_float
+    L.sky_scale_img.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, ip, ip, fp, vp]
+    L.sky_map_detections.argtypes = [vp, vp, ip, ip, ip, ip, ip, fp, ip, fp, fp, vp, ip, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.sky_tile_gather.argtypes = [vp, vp, ip, ip, ip, vp, ip, vp, ip, ip, ip, ip, vp]
     _lib = L
     return L
 

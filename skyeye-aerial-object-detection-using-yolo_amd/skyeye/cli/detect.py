@@ -12,7 +12,7 @@ from ..utils.torch_utils import select_device, time_sync
 
 @torch.no_grad()
 def run(weights=None, cfg="skyeye_s.yaml", source=None, imgsz=640, conf_thres=0.25, iou_thres=0.45, max_det=1000, device="",
-        classes=None, agnostic_nms=False, half=False, orig_shapes=None, nms_mode="corrected"):
+        classes=None, agnostic_nms=False, half=False, orig_shapes=None, nms_mode="corrected", augment=False):
     device = select_device(device)
     model = SkyEyeDetector(cfg)
     if weights:
@@ -32,7 +32,7 @@ def run(weights=None, cfg="skyeye_s.yaml", source=None, imgsz=640, conf_thres=0.
         im = torch.from_numpy(np.ascontiguousarray(frame)).to(device)[None]   # uint8 [1,3,H,W]; /255 in the engine (:131-135)
         t2 = time_sync()
         dt[0] += t2 - t1
-        pred, _ = model(im, augment=False, visualize=False)                   # detect.py:140
+        pred, _ = model(im, augment=augment, visualize=False)                 # detect.py:140
         t3 = time_sync()
         dt[1] += t3 - t2
         pred = non_max_suppression(pred, conf_thres, iou_thres, classes, agnostic_nms, max_det=max_det, mode=nms_mode)   # :145

@@ -18,7 +18,7 @@ from ..utils.torch_utils import select_device, time_sync
 
 @torch.no_grad()
 def validate(weights=None, cfg="skyeye_s.yaml", frames=None, batch_size=32, img_size=640, conf_thres=0.001, iou_thres=0.6,
-             half=True, device="", num_batches=4, multi_label=True, single_cls=False, nms_mode="literal", verbose=True):
+             half=True, device="", num_batches=4, multi_label=True, single_cls=False, nms_mode="literal", verbose=True, augment=False):
     device = select_device(device)                                           # validate.py:177
     model = SkyEyeDetector(cfg)
     if weights:
@@ -40,7 +40,7 @@ def validate(weights=None, cfg="skyeye_s.yaml", frames=None, batch_size=32, img_
         img = torch.from_numpy(frames[i:i + batch_size]).to(device, non_blocking=True)   # uint8; /255 happens in the engine (:236-238)
         t2 = time_sync()
         dt[0] += t2 - t1
-        out, _train_out = model(img, augment=False)                          # validate.py:245
+        out, _train_out = model(img, augment=augment)                        # validate.py:245
         t3 = time_sync()
         dt[1] += t3 - t2
         out = non_max_suppression(out, conf_thres, iou_thres, multi_label=multi_label, agnostic=single_cls, mode=nms_mode)   # :255
@@ -66,9 +66,10 @@ def parse_opt():
     p.add_argument("--iou-thres", type=float, default=0.6)
     p.add_argument("--device", default="")
     p.add_argument("--no-half", action="store_true")
+    p.add_argument("--augment", action="store_true", help="augmented inference (validate.py:123)")
     return p.parse_args()
 
 
 if __name__ == "__main__":
     o = parse_opt()
-    validate(o.weights, o.cfg, o.frames, o.batch_size, o.img_size, o.conf_thres, o.iou_thres, not o.no_half, o.device)
+    validate(o.weights, o.cfg, o.frames, o.batch_size, o.img_size, o.conf_thres, o.iou_thres, not o.no_half, o.device, augment=o.augment)

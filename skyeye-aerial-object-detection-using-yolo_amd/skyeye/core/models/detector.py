@@ -163,7 +163,12 @@ class SkyEyeDetector(NativeModule):
 
     def forward(self, x, augment=False, visualize=False):
         """eval: (detections [B, N, nc+5], [raw_P3, raw_P4, raw_P5]); train: raw list (detector.py:300-324).
-        ``augment`` / ``visualize`` are accepted because the reference's callers pass them (validate.py:245, detect.py:140)."""
+        ``augment`` / ``visualize`` are accepted because the reference's callers pass them (validate.py:245, detect.py:140);
+        ``augment=True`` (eval only) runs the 1 / 0.83-flipped / 0.67 schedule of ``skyeye.utils.tta.forward_augment`` and returns
+        (detections [B, sum N_i, nc+5] in the frame of ``x``, None)."""
+        if augment and not self.training:
+            from ...utils.tta import forward_augment
+            return forward_augment(lambda xi: self._run([xi])[0], x, gs=int(self.stride.max())), None
         outs = self._run([x])
         if not self.training:
             return outs[0], outs[1:]

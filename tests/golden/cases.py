@@ -131,3 +131,16 @@ NMS_CASES = [
     dict(name="corrected_mode_like", nc=10, batch=2, n=1500, seed=210,
          kwargs=dict(conf_threshold=0.1, iou_threshold=0.3)),
 ]
+
+
+# scale_img (torch_utils.py:262-288) cases of the test-time-augmentation front end:
+# name -> (B, H, W, ratio, flip dim of the caller (0 none / 2 / 3), same_shape, gs).  Inputs: seeded_input("tta." + name).
+TTA_CASES = {
+    "r083": (2, 64, 96, 0.83, 0, False, 32),
+    "r067_lr": (1, 64, 96, 0.67, 3, False, 32),
+    "r083_ud": (1, 96, 160, 0.83, 2, False, 32),
+    "r050_same": (1, 128, 128, 0.5, 0, True, 32),
+    "r067_gs64": (1, 160, 224, 0.67, 0, False, 64),
+    "r100": (1, 32, 64, 1.0, 0, False, 32),
+    "r083_big": (1, 640, 640, 0.83, 3, False, 32),
+}

@@ -16,6 +16,7 @@ What is executed from the reference, unmodified (file:line under /root/reference
   * skyeye/core/models/backbone.py   Backbone :12-99, SkyEyeBackbone :119-159
   * skyeye/core/models/detector.py   DetectionHead :18-145, FeatureNeck :148-231
   * skyeye/utils/metrics.py          non_max_suppression :361-457 (wrapper only)
+  * skyeye/utils/torch_utils.py      scale_img :262-288
 
 How the classes are composed (SURVEY.md Appendix A -- the reference's own
 ``SkyEyeDetector`` cannot be constructed or run):
@@ -364,8 +365,32 @@ def gen_eval():
     print(f"  eval: iou {out['iou.out'].shape} max {out['iou.out'].max():.6f}; ap_per_class ap {ap.shape} mean {ap.mean():.4f}")
 
 
+def gen_tta():
+    """scale_img torch_utils.py:262-288, unmodified, on ``x.flip(f)`` (the caller's flip of YOLOv5's _forward_augment, which the
+    reference's ``augment=`` flag, validate.py:245 / detect.py:140, stands for; the reference has no body for it)."""
+    import importlib
+    from cases import TTA_CASES
+    pkg = types.ModuleType("skyeye.utils")
+    pkg.__path__ = [os.path.join(REF, "skyeye", "utils")]
+    sys.modules["skyeye.utils"] = pkg
+    tu = importlib.import_module("skyeye.utils.torch_utils")
+    out = {}
+    for name, (B, H, W, ratio, flip, same, gs) in TTA_CASES.items():
+        x = torch.from_numpy(seeded_input("tta." + name, (B, 3, H, W), 7))
+        y = tu.scale_img(x.flip(flip) if flip else x, ratio, same_shape=same, gs=gs).numpy()
+        if name.endswith("_big"):                     # keep the file small: shape + sampled rows
+            out[name + ".shape"] = np.array(y.shape)
+            out[name + ".rows"] = y[:, :, ::37].copy()
+        else:
+            out[name] = y
+        print(f"  tta {name}: {tuple(x.shape)} -> {y.shape}")
+    np.savez_compressed(os.path.join(HERE, "tta.npz"), **out)
+
+
 def main(argv):
-    what = set(argv) or {"blocks", "detectors", "nms", "eval", "ha"}
+    what = set(argv) or {"blocks", "detectors", "nms", "eval", "ha", "tta"}
+    if "tta" in what:
+        gen_tta()
     if "eval" in what:
         gen_eval()
     if "ha" in what:
