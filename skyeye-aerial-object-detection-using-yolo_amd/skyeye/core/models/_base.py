@@ -170,8 +170,8 @@ class NativeModule(nn.Module):
             return ent[0]
         if ent is not None:
             ent[0].close()
-        if len(self._engines) >= 4:                       # keep a few geometries resident
-            _, (old, _) = self._engines.popitem()
+        if len(self._engines) >= 6:                       # keep a few geometries resident (test-time augmentation plans three)
+            old, _ = self._engines.pop(next(iter(self._engines)))     # the oldest plan goes first
             old.close()
         cfg = dict(self._sky_config())
         cfg.update(extra_cfg or {})
