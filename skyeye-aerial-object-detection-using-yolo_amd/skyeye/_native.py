@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libskyeye_hip.so")
+# SKYEYE_HIP_LIB: developer switch to load another build of the same library (A/B timing of a kernel change in one session)
+LIB_PATH = os.environ.get("SKYEYE_HIP_LIB") or os.path.join(_HERE, "_lib", "libskyeye_hip.so")
 
 SKY_MAX_LEVELS, SKY_MAX_ANCHORS, SKY_MAX_IO = 4, 8, 4
 SKY_F32, SKY_BF16 = 0, 1
