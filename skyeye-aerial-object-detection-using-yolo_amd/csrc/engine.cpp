@@ -443,12 +443,24 @@ static TV spp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, cons
     ConvOpt o1;
     o1.out_into = &s0;
     conv_block(c, p + "cv1.", x, cin, h, 1, 1, true, o1);
-    for (int i = 0; i < 3; ++i) {
+    // small maps (the 40 x 40 of a 1280-pixel frame): the three cascaded pools in one launch that reads cv1's slice once
+    static const bool no_pyramid = getenv("SKY_NO_SPP_PYRAMID") != nullptr;
+    const int vec = c.e.dtype == 0 ? 4 : 8;
+    if (!no_pyramid && h % (2 * vec) == 0 && (long)x.H * x.W * 2 <= 4096) {
         Op op;
         op.kind = OP_MAXPOOL5;
-        op.in = Ctx::slice(cat, i * h, h);
-        op.out = Ctx::slice(cat, (i + 1) * h, h);
+        op.win = 3;
+        op.in = Ctx::slice(cat, 0, h);
+        op.out = Ctx::slice(cat, h, 3 * h);
         c.push(op);
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            Op op;
+            op.kind = OP_MAXPOOL5;
+            op.in = Ctx::slice(cat, i * h, h);
+            op.out = Ctx::slice(cat, (i + 1) * h, h);
+            c.push(op);
+        }
     }
     ConvOpt o2;
     o2.out_into = out_into;
@@ -1176,6 +1188,11 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 break;
             }
             case OP_MAXPOOL5:
+                if (op.win == 3) {
+                    SKY_HIP(launch_spp_pyramid(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                               op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, op.in.C, s));
+                    break;
+                }
                 SKY_HIP(launch_maxpool5(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                         op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, s));
                 break;

@@ -244,6 +244,149 @@ __global__ void maxpool5_kernel(const T* __restrict__ src, int lds_, T* __restri
     }
 }
 
+// The whole SPP pyramid (5, 9 = 5o5, 13 = 5o5o5; blocks.py:142-147) of a small map in ONE launch: a workgroup owns one image
+// and two 16-byte channel vectors (32 contiguous bytes per pixel), keeps that plane in LDS and runs the three cascaded
+// separable 5-max passes on it (row pass -> registers -> LDS, column pass -> registers -> global + LDS); x is read once.
+// max is exact, so the result equals three maxpool5 launches (up to the sign of a zero that ties with the other zero).  Workgroups that share the cache lines of a
+// pixel (same image, neighbouring channel vectors) are placed on the same XCD (blockIdx % 8).
+// In LDS the plane holds ORDER KEYS: fp32 values as they are (v_max_f32), bf16 pairs mapped to unsigned 16-bit integers with the
+// same order (sign bit flipped for positives, all bits for negatives) so that one v_pk_max_u16 takes the max of two channels.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct PoolKey;
+template <> struct PoolKey<float> {
+    static __device__ __forceinline__ u32x4_t to_key(const u32x4_t& v) { return v; }
+    static __device__ __forceinline__ u32x4_t from_key(const u32x4_t& k) { return k; }
+    static __device__ __forceinline__ u32x4_t vmax(const u32x4_t& m, const u32x4_t& v)
+    {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(fmaxf(__uint_as_float(m[e]), __uint_as_float(v[e])));
+        return o;
+    }
+};
+template <> struct PoolKey<__bf16> {
+    static __device__ __forceinline__ unsigned flip(unsigned x, unsigned sign_halves)
+    {   // per 16-bit half: sign_halves has bit 0 / bit 16 set where ALL bits are flipped, elsewhere only the sign bit
+        return x ^ (((sign_halves << 16) - sign_halves) | 0x80008000u);
+    }
+    static __device__ __forceinline__ u32x4_t to_key(const u32x4_t& v)
+    {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = flip(v[e], (v[e] >> 15) & 0x00010001u);            // negative: flip everything
+        return o;
+    }
+    static __device__ __forceinline__ u32x4_t from_key(const u32x4_t& k)
+    {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = flip(k[e], (~k[e] >> 15) & 0x00010001u);          // key below 0x8000: was negative
+        return o;
+    }
+    static __device__ __forceinline__ u32x4_t vmax(const u32x4_t& m, const u32x4_t& v)
+    {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned a = m[e], b = v[e];     // scalars first: __builtin_bit_cast of a vector ELEMENT reference is miscompiled
+            const u16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b));
+            o[e] = __builtin_bit_cast(unsigned, r);
+        }
+        return o;
+    }
+};
+
+static constexpr int SPP_CG = 2;       // 16-byte channel vectors per workgroup
+static constexpr int SPP_ITEMS = 16;   // (pixel, vector) items per thread at most: H * W * SPP_CG <= 256 * 16
+
+template <typename T>
+__global__ void __launch_bounds__(256) spp_pyramid_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, int B, int H, int W,
+                                                          int C, int level_stride)
+{
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char spp_smem[];
+    u32x4_t* tile = reinterpret_cast<u32x4_t*>(spp_smem);
+    const int ncg = C / (N * SPP_CG);
+    const int q = blockIdx.x >> 3;
+    const int g = q % ncg, b = (blockIdx.x & 7) + 8 * (q / ncg);
+    if (b >= B) return;                                            // uniform per workgroup
+    const int npx = H * W, tot = npx * SPP_CG, tid = threadIdx.x;
+    const T* in = src + (long)b * npx * lds_ + g * SPP_CG * N;
+    T* out = dst + (long)b * npx * ldd + g * SPP_CG * N;
+    u32x4_t r[SPP_ITEMS];
+    int py[SPP_ITEMS], px[SPP_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SPP_ITEMS; ++k) {
+        const int idx = tid + k * 256;
+        const int p = idx / SPP_CG;
+        py[k] = p / W;
+        px[k] = p - py[k] * W;
+        if (idx < tot) tile[idx] = PoolKey<T>::to_key(*reinterpret_cast<const u32x4_t*>(in + (long)p * lds_ + (idx % SPP_CG) * N));
+    }
+    __syncthreads();
+    for (int level = 0; level < 3; ++level) {
+#pragma unroll
+        for (int k = 0; k < SPP_ITEMS; ++k) {                      // row pass
+            const int idx = tid + k * 256;
+            if (idx < tot) {
+                const int v = idx % SPP_CG, rowb = py[k] * W;
+                u32x4_t m = tile[idx];
+#pragma unroll
+                for (int d = -2; d <= 2; ++d) {
+                    if (d == 0) continue;
+                    int xx = px[k] + d;
+                    xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                    m = PoolKey<T>::vmax(m, tile[(rowb + xx) * SPP_CG + v]);
+                }
+                r[k] = m;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPP_ITEMS; ++k)
+            if (tid + k * 256 < tot) tile[tid + k * 256] = r[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPP_ITEMS; ++k) {                      // column pass
+            const int idx = tid + k * 256;
+            if (idx < tot) {
+                const int v = idx % SPP_CG;
+                u32x4_t m = r[k];
+#pragma unroll
+                for (int d = -2; d <= 2; ++d) {
+                    if (d == 0) continue;
+                    int yy = py[k] + d;
+                    yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                    m = PoolKey<T>::vmax(m, tile[(yy * W + px[k]) * SPP_CG + v]);
+                }
+                r[k] = m;
+                *reinterpret_cast<u32x4_t*>(out + (long)level * level_stride + (long)(idx / SPP_CG) * ldd + v * N) = PoolKey<T>::from_key(m);
+            }
+        }
+        if (level == 2) break;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPP_ITEMS; ++k)
+            if (tid + k * 256 < tot) tile[tid + k * 256] = r[k];
+        __syncthreads();
+    }
+}
+
+// dst = the first pooled slice; slices 2 and 3 follow at `level_stride` elements.  hipErrorNotSupported when the plane does not
+// fit (the caller then issues three launch_maxpool5).
+hipError_t launch_spp_pyramid(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int level_stride, hipStream_t s)
+{
+    const int N = dtype == 0 ? 4 : 8;
+    if (C % (N * SPP_CG) != 0 || (long)H * W * SPP_CG > 256L * SPP_ITEMS) return hipErrorNotSupported;
+    const size_t lds = (size_t)H * W * SPP_CG * 16;
+    const int grid = 8 * (C / (N * SPP_CG)) * ((B + 7) / 8);
+    if (dtype == 0)
+        hipLaunchKernelGGL(spp_pyramid_kernel<float>, dim3(grid), dim3(256), lds, s, (const float*)src, lds_, (float*)dst, ldd, B, H, W, C, level_stride);
+    else
+        hipLaunchKernelGGL(spp_pyramid_kernel<__bf16>, dim3(grid), dim3(256), lds, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C, level_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, hipStream_t s)
 {
     const int N = dtype == 0 ? 4 : 8;

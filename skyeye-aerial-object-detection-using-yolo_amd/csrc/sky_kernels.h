@@ -93,6 +93,8 @@ hipError_t launch_import(int dtype, const void* src, int src_u8, int src_nhwc, v
 // engine NHWC T -> caller NCHW fp32
 hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s);
 // MaxPool2d(5, stride 1, pad 2), -inf padding (blocks.py:142-144; 9 = 5o5, 13 = 5o5o5 exactly)
+hipError_t launch_spp_pyramid(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int level_stride,
+                              hipStream_t s);
 hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C,
                            hipStream_t s);
 // F.interpolate(mode='nearest') (detector.py:214,218), generic sizes
