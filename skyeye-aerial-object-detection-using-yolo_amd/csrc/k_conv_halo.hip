@@ -23,6 +23,10 @@
 //   * one barrier per tap (64-byte K-steps x 2); the next slab's DMA is issued right after it.
 #include "sky_kernels.h"
 
+#ifndef SKY_HALO_VGPR
+#define SKY_HALO_VGPR 256      // VGPR budget of conv_halo_kernel (experiments: -DSKY_HALO_VGPR=N)
+#endif
+
 #include "conv_frag.h"
 
 #include <stdio.h>
@@ -82,6 +86,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
     constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
     const bool has_res = a.res != nullptr;
     const int nl0 = nlane % (NF * 16);            // channel within the workgroup's N tile (bias in LDS)
+    // STORE-DATA HAZARD (measured, tests/test_gpu_determinism.py): hipcc packs the output vector in place over the accumulator
+    // registers, issues buffer_store_dwordx4 from them and lets the very next ds_read_b128 (the bias of the following channel
+    // group) return INTO the same registers.  With two 256-VGPR workgroups per CU the store queue backs up, the store reads its
+    // data late and sent bias bits instead of outputs for a few lanes.  `pin` keeps the previous store's data registers live until
+    // the following LDS / residual loads have been consumed, so their destinations cannot be those registers.
+    u32x4_t pin = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int ty, tx;
@@ -128,6 +138,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     for (int e = 0; e < 8; ++e) v[e] += __uint_as_float(rv[s][e >> 2][e & 3]);
                 }
             }
+            asm volatile("; previous store data live until here" ::"v"(pin));      // bias + residual of this group are in
             if (sizeof(T) == 2) {
                 u32x4_t o;
 #pragma unroll
@@ -136,6 +147,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB, 0);
+                pin = o;
                 if (FC > 0 && s < FC / 32) bop[i][s][0] = o;
             } else {
 #pragma unroll
@@ -144,6 +156,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
                     __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB + h * 16, 0);
+                    if (h == 1) pin = o;
                     if (FC > 0 && s < FC / 32) bop[i][s][h] = o;
                 }
             }
@@ -168,16 +181,16 @@ __device__ __forceinline__ TapStep tap_step(int q)
 }
 
 template <typename T, int NF, bool SQ, bool S2, int FC = 0>
-__global__ void __launch_bounds__(HWV * 64, 2) conv_halo_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SKY_HALO_VGPR))) conv_halo_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
     constexpr int WSLAB = NB * 128;               // bytes of one weight slab
     constexpr int WDMA = NB / 8 / HWV;            // weight DMA instructions per wave per slab (8 rows each)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* const halo = smem;
-    char* const wring = smem + HALO_BYTES;
-    float* const lbias = reinterpret_cast<float*>(smem + HALO_BYTES + 2 * WSLAB);
-    char* const w2lds = smem + HALO_BYTES + 2 * WSLAB + NB * 4;                   // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
+    char* const halo = smem + (((a.dbg >> 16) & 0xff) << 10);      // experiment: SKY_CONV_DBG bits 16..23 = KB of padding in front
+    char* const wring = halo + HALO_BYTES;
+    float* const lbias = reinterpret_cast<float*>(halo + HALO_BYTES + 2 * WSLAB);
+    char* const w2lds = halo + HALO_BYTES + 2 * WSLAB + NB * 4;                   // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
     float* const b2lds = reinterpret_cast<float*>(w2lds + FC * FC * (int)sizeof(T));
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(b2lds + (FC ? FC : 0));   // 64 x 8 B, experiments only
 
@@ -798,7 +811,14 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     const char* dbg = getenv("SKY_CONV_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
     constexpr int NB = NF * 16;
-    const size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0) + ((a.dbg & 256) ? 512 : 0);
+    size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0) + ((a.dbg & 256) ? 512 : 0) + ((size_t)((a.dbg >> 16) & 0xff) << 10);
+    // 128-channel tiles (256 VGPRs, 78 KB of LDS): ONE workgroup per CU.  Two co-resident ones produced, run to run, zeroed output
+    // vectors in the first tile of the later workgroup (tests/test_gpu_determinism.py).  The LDS request
+    // above half of the CU's 160 KB makes the exclusion a hardware guarantee rather than a property of the grid size.
+    const char* nf8_env = getenv("SKY_HALO_NF8");
+    const bool nf8_pair = nf8_env && nf8_env[0] == 'p';      // "pair": the faulty mode, experiments only
+    const bool solo = NF == 8 && !nf8_pair;
+    if (solo && lds < 84 * 1024) lds = 84 * 1024;
     auto kern = conv_halo_kernel<T, NF, SQ, S2, FC>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -814,7 +834,8 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
     // two workgroups per CU in total: with several N tiles the tile range is split over fewer, longer-lived workgroups
     const int gy = a.Cout / NB;
-    const int slots = getenv("SKY_STREAM_OLDGRID") ? 2 * n_cu : (2 * n_cu / gy > 0 ? 2 * n_cu / gy : 1);
+    const int per_cu = solo ? 1 : 2;
+    const int slots = getenv("SKY_STREAM_OLDGRID") ? per_cu * n_cu : (per_cu * n_cu / gy > 0 ? per_cu * n_cu / gy : 1);
     int gx = ntile < slots ? ntile : slots;
     if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
     static unsigned long long* stamps = nullptr;
@@ -973,6 +994,18 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
     const char* mode = getenv("SKY_CONV_HALO");   // "0": never, "force": whenever the shape is covered
     if (mode && mode[0] == '0') return hipErrorNotSupported;
+    {   // bisection switch: SKY_HALO_SKIP bit 0 = stride-1 kernel, 1 = stride-2 kernel, 2 = narrow kernels, 3 = 128-channel tiles, 4 = 64-channel tiles
+        static const int skip = getenv("SKY_HALO_SKIP") ? atoi(getenv("SKY_HALO_SKIP")) : 0;
+        if (small ? (skip & 4) : (a.stride == 2 ? (skip & 2) : (skip & 1))) return hipErrorNotSupported;
+        if (!small && ((a.Cout % 128 == 0) ? (skip & 8) : (skip & 16))) return hipErrorNotSupported;
+    }
+    // The stride-2 mode is OPT-IN (SKY_CONV_HALO=force or SKY_HALO_S2=1): with two resident workgroups per CU it has produced,
+    // run to run, a few zeroed output vectors in the first tile of the later workgroups (tests/test_gpu_determinism.py; root
+    // cause open).  Stride-2 3x3 layers take the streaming kernel until that is understood.
+    if (!small && a.stride == 2) {
+        const bool s2_on = getenv("SKY_HALO_S2") != nullptr;
+        if (!s2_on && !(mode && mode[0] == 'f')) return hipErrorNotSupported;
+    }
     const double cover = pick_tile(a, small ? SPX : HPIX);
     // partially filled tiles waste matrix work: keep the streaming kernel when less than 3/4 of the tile grid is image
     if (!(mode && mode[0] == 'f') && cover < 0.75) return hipErrorNotSupported;
@@ -982,7 +1015,10 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         if (e == hipSuccess && variant) *variant = 5000 + nb;
         return e;
     }
-    const int nb = a.Cout % 128 == 0 ? 128 : 64;
+    // 64-channel tiles (two workgroups per CU) everywhere by default: measured faster than 128-channel tiles alone on a CU
+    // (3x3 128->128 @80x80: 82 vs 96 us; the faulty pair mode ran 74.5 us).  SKY_HALO_NF8=solo|pair selects the 128-channel tiles.
+    const bool nf8 = getenv("SKY_HALO_NF8") != nullptr;       // read per launch: the parity tests switch it
+    const int nb = (a.Cout % 128 == 0 && nf8) ? 128 : 64;
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
     if (a.stride == 2) {

@@ -1,0 +1,61 @@
+"""BASELINE.json's full size (skyeye_s, 32 frames of 1280 x 1280, bf16 engine) through size-independent properties: the batch
+path does not mix frames (frame i of the batch == the same frame run alone, bit for bit), the fused decode equals the
+standalone decode of the raw logits, the uint8 and float input contracts agree, everything is finite.  The fp32 engine at
+this size is pinned against the reference fixture in test_gpu_detector.py (case s_1280)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_detector, detector_params, variant_cfg
+from seeded import seeded_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = build_detector(variant_cfg("skyeye_s"))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params("skyeye_s").items()}, strict=True)
+    return m.eval().set_precision("bf16")
+
+
+def test_batch_of_32_equals_single_frames(model):
+    frames = seeded_scene(32, 1280, 1280, 77)
+    x = torch.from_numpy(frames).cuda()
+    det, raw = model(x)
+    det_again, _ = model(x)
+    assert torch.equal(det, det_again), "two runs of the same batch differ"
+    assert det.shape == (32, 100800, 15) and [tuple(r.shape) for r in raw] == [(32, 3, 160, 160, 15), (32, 3, 80, 80, 15), (32, 3, 40, 40, 15)]
+    assert bool(torch.isfinite(det).all())
+    for i in (0, 13, 31):
+        d1, r1 = model(x[i:i + 1])
+        assert torch.equal(d1[0], det[i]), f"frame {i}: batch result differs from the single-frame result"
+        for a, b in zip(r1, raw):
+            assert torch.equal(a[0], b[i])
+    # the decode fused into the detection convolutions == DetectionHead.process_detections on the raw logits (detector.py:88-145)
+    assert torch.equal(model.detection_head.process_detections(raw, (1280, 1280)), det)
+    # objectness / class scores are sigmoids, boxes positive sizes
+    assert float(det[..., 4:].min()) >= 0.0 and float(det[..., 4:].max()) <= 1.0 and float(det[..., 2:4].min()) >= 0.0
+
+
+def test_uint8_and_float_frames_agree_at_full_size(model):
+    frames = seeded_scene(2, 1280, 1280, 78)
+    a, _ = model(torch.from_numpy(frames).cuda())
+    b, _ = model(torch.from_numpy(frames.astype(np.float32) / np.float32(255.0)).cuda())
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant,batch,size", [("skyeye_l", 8, 640), ("skyeye_s_ha", 8, 640), ("skyeye_s_enh", 8, 640)])
+def test_other_variants_are_deterministic_and_batch_independent(variant, batch, size):
+    """Every kernel family of the wider graphs (skyeye_l's 64..1024-channel layers, the attention heads, cross-layer attention):
+    two runs agree bit for bit and frame i of the batch equals the frame run alone."""
+    from helpers import variant_enhanced
+    m = build_detector(variant_cfg(variant), variant_enhanced(variant))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params(variant).items()}, strict=True)
+    m.eval().set_precision("bf16")
+    x = torch.from_numpy(seeded_scene(batch, size, size, 79)).cuda()
+    a, _ = m(x)
+    b, _ = m(x)
+    assert torch.equal(a, b), f"{variant}: two runs of the same batch differ in {int((a != b).sum())} values"
+    one, _ = m(x[batch - 1:])
+    assert torch.equal(one[0], a[batch - 1]), f"{variant}: last frame of the batch differs from the frame run alone"
