@@ -86,11 +86,13 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
     constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
     const bool has_res = a.res != nullptr;
     const int nl0 = nlane % (NF * 16);            // channel within the workgroup's N tile (bias in LDS)
-    // STORE-DATA HAZARD (measured, tests/test_gpu_determinism.py): hipcc packs the output vector in place over the accumulator
-    // registers, issues buffer_store_dwordx4 from them and lets the very next ds_read_b128 (the bias of the following channel
-    // group) return INTO the same registers.  With two 256-VGPR workgroups per CU the store queue backs up, the store reads its
-    // data late and sent bias bits instead of outputs for a few lanes.  `pin` keeps the previous store's data registers live until
-    // the following LDS / residual loads have been consumed, so their destinations cannot be those registers.
+    // STORE-DATA HAZARD (found in r01_k, tests/test_gpu_determinism.py): the channel-group constant of a store must go into the
+    // VECTOR offset (folded by hipcc into the instruction's immediate), never into `soffset`.  A constant above 64 is not an inline
+    // operand, lands in an SGPR, and LLVM's hazard recognizer assumes that a MUBUF store with a REGISTER soffset needs no wait state
+    // before its data VGPRs are overwritten; it then scheduled the accumulator clear (v_mov v4, 0) directly behind
+    // buffer_store_dwordx4 v[4:7] of the last vector of a tile.  On gfx950 with two workgroups per CU contending for the vector
+    // memory path the store read lanes 12..15 of its first dword after that clear: zeros (bias bits in general) in the output.
+    // `pin` additionally keeps the previous store's registers live across the next bias / residual loads.
     u32x4_t pin = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -99,7 +101,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
         const int oy = y0 + ty, ox = x0 + tx;
         const bool ok = ty >= 0 && oy < a.Ho && ox < a.Wo;
         const int m = (bimg * a.Ho + oy) * a.Wo + ox;
-        const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(T) : -1;
+        // masked lanes: offset 0x80000000 stays out of range after the per-group constant is added (see the store below)
+        const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(T) : (int)0x80000000;
         u32x4_t rv[NF / 2][VB / 16];
         if (has_res) {
             const int roff = ok ? (m * a.ldr + nlane) * (int)sizeof(T) : -1;
@@ -146,7 +149,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
                     o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff + s * 4 * VB, 0, 0);
                 pin = o;
                 if (FC > 0 && s < FC / 32) bop[i][s][0] = o;
             } else {
@@ -155,7 +158,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     u32x4_t o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
-                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff, s * 4 * VB + h * 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff + s * 4 * VB + h * 16, 0, 0);
                     if (h == 1) pin = o;
                     if (FC > 0 && s < FC / 32) bop[i][s][h] = o;
                 }
@@ -812,12 +815,9 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     a.dbg = dbg ? atoi(dbg) : 0;
     constexpr int NB = NF * 16;
     size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0) + ((a.dbg & 256) ? 512 : 0) + ((size_t)((a.dbg >> 16) & 0xff) << 10);
-    // 128-channel tiles (256 VGPRs, 78 KB of LDS): ONE workgroup per CU.  Two co-resident ones produced, run to run, zeroed output
-    // vectors in the first tile of the later workgroup (tests/test_gpu_determinism.py).  The LDS request
-    // above half of the CU's 160 KB makes the exclusion a hardware guarantee rather than a property of the grid size.
+    // SKY_HALO_NF8=solo (experiments): 128-channel tiles alone on a CU -- an LDS request above half of the CU's 160 KB excludes a second one
     const char* nf8_env = getenv("SKY_HALO_NF8");
-    const bool nf8_pair = nf8_env && nf8_env[0] == 'p';      // "pair": the faulty mode, experiments only
-    const bool solo = NF == 8 && !nf8_pair;
+    const bool solo = NF == 8 && nf8_env && nf8_env[0] == 's';
     if (solo && lds < 84 * 1024) lds = 84 * 1024;
     auto kern = conv_halo_kernel<T, NF, SQ, S2, FC>;
     static bool attr_done = false;
@@ -999,12 +999,9 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         if (small ? (skip & 4) : (a.stride == 2 ? (skip & 2) : (skip & 1))) return hipErrorNotSupported;
         if (!small && ((a.Cout % 128 == 0) ? (skip & 8) : (skip & 16))) return hipErrorNotSupported;
     }
-    // The stride-2 mode is OPT-IN (SKY_CONV_HALO=force or SKY_HALO_S2=1): with two resident workgroups per CU it has produced,
-    // run to run, a few zeroed output vectors in the first tile of the later workgroups (tests/test_gpu_determinism.py; root
-    // cause open).  Stride-2 3x3 layers take the streaming kernel until that is understood.
-    if (!small && a.stride == 2) {
-        const bool s2_on = getenv("SKY_HALO_S2") != nullptr;
-        if (!s2_on && !(mode && mode[0] == 'f')) return hipErrorNotSupported;
+    if (!small && a.stride == 2) {      // A/B switch: SKY_HALO_S2=0 sends stride-2 layers to the streaming kernel
+        const char* s2 = getenv("SKY_HALO_S2");
+        if (s2 && s2[0] == '0') return hipErrorNotSupported;
     }
     const double cover = pick_tile(a, small ? SPX : HPIX);
     // partially filled tiles waste matrix work: keep the streaming kernel when less than 3/4 of the tile grid is image
@@ -1015,10 +1012,10 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         if (e == hipSuccess && variant) *variant = 5000 + nb;
         return e;
     }
-    // 64-channel tiles (two workgroups per CU) everywhere by default: measured faster than 128-channel tiles alone on a CU
-    // (3x3 128->128 @80x80: 82 vs 96 us; the faulty pair mode ran 74.5 us).  SKY_HALO_NF8=solo|pair selects the 128-channel tiles.
-    const bool nf8 = getenv("SKY_HALO_NF8") != nullptr;       // read per launch: the parity tests switch it
-    const int nb = (a.Cout % 128 == 0 && nf8) ? 128 : 64;
+    // 128-channel tiles where Cout allows (two workgroups per CU).  A/B switches: SKY_HALO_NF8=off -> 64-channel tiles everywhere,
+    // SKY_HALO_NF8=solo -> 128-channel tiles alone on a CU (3x3 128->128 @80x80: 74.5 us default, 82 us off, 96 us solo)
+    const char* nf8_sel = getenv("SKY_HALO_NF8");
+    const int nb = (a.Cout % 128 == 0 && !(nf8_sel && nf8_sel[0] == 'o')) ? 128 : 64;
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
     if (a.stride == 2) {

@@ -50,17 +50,13 @@ def _oracle():
 
 
 def _run(module, x, mode):
-    # "force" also selects the opt-in forms (128-channel tiles alone on a CU, stride-2 mode) so that they stay parity-tested
     os.environ["SKY_CONV_HALO"] = mode
-    if mode == "force":
-        os.environ["SKY_HALO_NF8"] = "solo"
     try:
         y = module(x)
         torch.cuda.synchronize()
         return y.cpu().numpy()
     finally:
         os.environ.pop("SKY_CONV_HALO", None)
-        os.environ.pop("SKY_HALO_NF8", None)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -140,21 +136,15 @@ def test_halo_kernel_is_what_ran():
     m = load_seeded(M.ConvolutionBlock(64, 128, 3, 1), 79).set_precision("bf16")
     x = torch.randn(2, 64, 32, 32, device="cuda")
     os.environ["SKY_CONV_HALO"] = "force"
-    os.environ["SKY_HALO_NF8"] = "solo"
     try:
         m(x)
         h = m._engine([x])
         outs = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in h.output_shapes()]
         prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=1)
-        tags = [t for _, _, t in prof]
-        assert any(t % 10000 == 4128 for t in tags), f"128-channel halo kernel did not run: tags {tags}"
-        os.environ.pop("SKY_HALO_NF8", None)
-        prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=1)
-        tags = [t for _, _, t in prof]
-        assert any(t % 10000 == 4064 for t in tags), f"default: 64-channel halo tiles, two workgroups per CU: tags {tags}"
     finally:
         os.environ.pop("SKY_CONV_HALO", None)
-        os.environ.pop("SKY_HALO_NF8", None)
+    tags = [t for _, _, t in prof]
+    assert any(t % 10000 == 4128 for t in tags), f"halo kernel did not run: tags {tags}"
 
 
 def test_stride2_halo_kernel_is_what_ran():
@@ -165,14 +155,7 @@ def test_stride2_halo_kernel_is_what_ran():
     outs = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in h.output_shapes()]
     prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=1)
     tags = [t for _, _, t in prof]
-    assert not any(t % 10000 // 1000 == 6 for t in tags), f"the stride-2 halo mode is opt-in (SKY_HALO_S2 / force): tags {tags}"
-    os.environ["SKY_HALO_S2"] = "1"
-    try:
-        prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=1)
-    finally:
-        os.environ.pop("SKY_HALO_S2", None)
-    tags = [t for _, _, t in prof]
-    assert any(t % 10000 == 6064 for t in tags), f"stride-2 halo kernel did not run: tags {tags}"
+    assert any(t % 10000 == 6128 for t in tags), f"stride-2 halo kernel did not run: tags {tags}"
 
 
 def test_narrow_halo_kernel_is_what_ran():

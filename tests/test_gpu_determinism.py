@@ -1,7 +1,8 @@
 """Large-grid behaviour of the convolution kernels: run-to-run determinism and agreement with a plain PyTorch fp32 convolution
 on the same bf16-rounded operands, at batch sizes where every CU holds two workgroups and each workgroup walks several
-tiles.  The small parity cases cannot see scheduling-dependent faults: the stride-2 mode of the halo kernel passed all of them
-and still zeroed a few output vectors per launch at B = 32 (it is opt-in since)."""
+tiles.  The small parity cases cannot see scheduling-dependent faults: the 128-channel halo tiles passed all of them while a
+store-data hazard (register `soffset` on the last vector store of a tile) zeroed a few output vectors per
+launch at B = 32."""
 import numpy as np
 import pytest
 import torch
