@@ -44,3 +44,57 @@ def test_conv_is_deterministic_and_matches_torch(cin, cout, k, stride, hw, batch
     assert err <= 0.02 * scale, f"max |engine - torch| = {err:.4f} at scale {scale:.2f}"      # bf16 output rounding: 2^-9 relative
     lost = int(((got == 0) & (ref.abs() > 0.05 * scale)).sum())
     assert lost == 0, f"{lost} outputs are exactly zero where the reference is not"
+
+
+def _repeat_equal(fn, n=3):
+    outs = [fn().clone() for _ in range(n)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), f"{int((outs[0] != o).sum())} elements differ between two runs"
+    return outs[0]
+
+
+def test_opt_in_conv_forms_are_deterministic_at_large_grids():
+    """The forms the default dispatch does not take -- narrow stride-2 halo kernel (SKY_CONV_HALO=force), the fused 1x1 epilogue
+    (SKY_FUSE=1), 64-channel tiles for 128-channel layers (SKY_HALO_NF8=off) -- under the same two-workgroups-per-CU load."""
+    import os
+    import skyeye.core.models as M
+    torch.manual_seed(5)
+    x = torch.randn(16, 32, 320, 320, device="cuda")
+    os.environ["SKY_CONV_HALO"] = "force"
+    try:
+        m = ConvolutionBlock(32, 64, 3, 2).eval().set_precision("bf16")
+        got = _repeat_equal(lambda: m(x))
+    finally:
+        os.environ.pop("SKY_CONV_HALO", None)
+    w = (m.conv.weight.detach().float().cuda() / np.float32(np.sqrt(1.0 + 1e-5))).bfloat16().float()
+    ref = F.silu(F.conv2d(x.bfloat16().float(), w, stride=2, padding=1))
+    assert float((got - ref).abs().max()) <= 0.02 * float(ref.abs().max())
+    os.environ["SKY_FUSE"] = "1"
+    try:
+        csp = M.CSPBlock(128, 128, 3, True, 0.5).eval().set_precision("bf16")
+        xc = torch.randn(32, 128, 80, 80, device="cuda")
+        fused = _repeat_equal(lambda: csp(xc))
+    finally:
+        os.environ.pop("SKY_FUSE", None)
+    assert bool(torch.isfinite(fused).all())
+    os.environ["SKY_HALO_NF8"] = "off"
+    try:
+        m2 = ConvolutionBlock(128, 128, 3, 1).eval().set_precision("bf16")
+        x2 = torch.randn(32, 128, 80, 80, device="cuda")
+        _repeat_equal(lambda: m2(x2))
+    finally:
+        os.environ.pop("SKY_HALO_NF8", None)
+
+
+def test_attention_cores_are_deterministic_at_large_grids():
+    import skyeye.core.models as M
+    torch.manual_seed(6)
+    t = M.TransformerLayer(256, 8).eval().set_precision("bf16")
+    x = torch.randn(16, 256, 40, 40, device="cuda")
+    a = _repeat_equal(lambda: t(x))
+    one = t(x[15:])
+    assert torch.equal(one[0], a[15]), "TransformerLayer: batch entry differs from the entry run alone"
+    wsa = M.WindowedSelfAttention(128, 8, 4).eval().set_precision("bf16")
+    xw = torch.randn(4096, 64, 128, device="cuda")            # 4096 windows of 8 x 8 tokens
+    b = _repeat_equal(lambda: wsa(xw))
+    assert torch.equal(wsa(xw[:7])[3], b[3])
