@@ -98,3 +98,18 @@ def test_attention_cores_are_deterministic_at_large_grids():
     xw = torch.randn(4096, 64, 128, device="cuda")            # 4096 windows of 8 x 8 tokens
     b = _repeat_equal(lambda: wsa(xw))
     assert torch.equal(wsa(xw[:7])[3], b[3])
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw,batch", [(128, 128, 3, 1, 80, 16), (64, 64, 3, 1, 160, 8), (128, 256, 3, 2, 80, 16), (256, 256, 1, 1, 80, 16)],
+                         ids=["128to128_k3", "64to64_k3", "128to256_k3s2", "256to256_k1"])
+def test_fp32_engine_is_deterministic_and_matches_torch(cin, cout, k, stride, hw, batch):
+    """The exact (fp32 MFMA) instantiations of the same kernels under the same load: bit-identical runs, 1e-4 of the output range
+    against torch's fp32 convolution (summation order only)."""
+    torch.manual_seed(cin + cout + k)
+    m = ConvolutionBlock(cin, cout, k, stride).eval().set_precision("fp32")
+    x = torch.randn(batch, cin, hw, hw, device="cuda")
+    got = _repeat_equal(lambda: m(x))
+    w = m.conv.weight.detach().float().cuda() / np.float32(np.sqrt(1.0 + 1e-5))
+    torch.backends.cudnn.allow_tf32 = False
+    ref = F.silu(F.conv2d(x, w, stride=stride, padding=k // 2))
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
