@@ -13,7 +13,11 @@ which ``tests/golden/make_golden.py`` produced by executing the reference's
 own PyTorch classes in the build container (``tests/test_oracle_golden.py``),
 EXCEPT the greedy suppression inside ``non_max_suppression`` (third-party
 ``torchvision.ops.nms``, absent and un-pinned upstream): PARITY UNPINNED there,
-see ``sky_oracle_nms.c``.
+see ``sky_oracle_nms.c``.  Front-end helpers at the end of the file: ``scale_img`` is pinned by
+``tests/golden/tta.npz`` (the reference's own function, 5e-7 absolute); ``letterbox_pixels`` restates OpenCV's
+fixed-point resize and is UNPINNED (cv2 is not installed, the reference holds no image fixtures); ``map_detections`` /
+``tta_forward`` / ``tile_origins`` / ``tile_gather`` are build-defined (the reference has the ``augment=`` flag but no
+body for it, and no tiling) and serve as the arithmetic the HIP kernels are compared with bit for bit.
 
 Weights arrive as ``{state_dict_name: ndarray}`` with the reference's names
  and a prefix per sub-module.
