@@ -6,15 +6,26 @@ uint8 frames -> SkyEyeDetector.forward (backbone, neck, heads, decode) -> non_ma
 drop-in Python API (skyeye.core.models / skyeye.utils.metrics), i.e. through the C ABI of libskyeye_hip.so.
 
     python bench.py                                  # 1 GPU, BASELINE.json configs[1]: skyeye_s bf16 B=32 @1280x1280
+    python bench.py --gpus N                         # spawns `python -m torch.distributed.run --nproc-per-node N` itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --model skyeye_s_ha              # config 3 (attention heads on)
+    python bench.py --model skyeye_l                 # config 4, one GPU's shard
+    python bench.py --model skyeye_l --precision fp8 --size 1536   # config 5, one GPU's shard
 
 N > 1: one process per GPU, every rank runs the same per-GPU batch (weak scaling, images are independent units),
 then an RCCL all-gather of the fixed-capacity box buffers so every rank holds all results (BASELINE north_star).
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+
+`roofline` is a fixed instrument: `frac` = END-TO-END MFMA fraction by SURVEY 8(d)'s formula,
+frames/s per GPU x GFLOP/frame / dense MFMA peak of the dtype; `families` lists every kernel family of the forward with BOTH
+its HBM fraction (algorithmic bytes / time / 8 TB/s) and its MFMA fraction, measured with hipEvents recorded inside
+libskyeye_hip.so on the stream the kernels run on (sky_profile_forward); `dominant` is the family with the largest summed
+time; `traffic` / per-family `pmc_bytes` come from the latest committed PMC pass (profiles/*pmc_traffic.json).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,13 +35,10 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "g
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_HBM_GBPS = 8000.0                            # HBM3E spec peak (same table)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBPS = 8000.0                                          # HBM3E spec peak (same table)
 GFLOP_PER_FRAME = {("skyeye_s", 1280): 83.0, ("skyeye_l", 1280): 459.7, ("skyeye_s", 640): 20.75,
-                   ("skyeye_l", 1536): 661.9}     # BASELINE.md section 3
+                   ("skyeye_l", 1536): 661.9}                   # BASELINE.md section 3
 
 
 def parse():
@@ -41,17 +49,43 @@ def parse():
     ap.add_argument("--model", default="skyeye_s")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=1280)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--conf", type=float, default=0.25)
     ap.add_argument("--iou", type=float, default=0.45)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--with-raw", action="store_true", help="also write the three raw detection levels (the reference's second return value)")
     return ap.parse_args()
+
+
+def spawn_workers(a):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD (never exec: this process may
+    already have touched the GPU) and relay its JSON line and exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line:
+        print(line)
+    elif r.stdout:
+        sys.stderr.write(r.stdout[-4000:])
+    raise SystemExit(r.returncode if r.returncode or line else 1)
 
 
 def build_model(name, precision, device):
     """name: a tests/golden/cases.py variant -- skyeye_s / _m / _l, skyeye_s_enh (cross-layer attention), skyeye_s_ha
     (config 3: windowed attention on P3 / P4 + transformer layer on P5 ahead of the detection convs)."""
+    import numpy as np
+    import torch
     from helpers import build_detector, detector_params, variant_cfg, variant_enhanced
     P = detector_params(name)
     model = build_detector(variant_cfg(name), variant_enhanced(name))
@@ -62,6 +96,8 @@ def build_model(name, precision, device):
 
 def calibrate_objectness(model, x, target=0.01, conf=0.25):
     """Shift the objectness biases so that ~1% of the boxes pass conf (realistic NMS load)."""
+    import numpy as np
+    import torch
     _, raw = model(x[:2])
     obj = torch.cat([r[..., 4].reshape(-1) for r in raw]).float()
     k = max(1, int(obj.numel() * target))
@@ -75,32 +111,78 @@ def calibrate_objectness(model, x, target=0.01, conf=0.25):
     return shift
 
 
+FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded by launch_conv)
+    ("halo3x3", "conv_halo_kernel: 3x3 halo tile + weight ring (stride 1 and 2)", lambda v: 4000 <= v < 5000 or 6000 <= v < 7000),
+    ("halo_narrow", "conv_halo_small_kernel: stem / narrow-input 3x3, K resident", lambda v: 5000 <= v < 6000),
+    ("halo_cv1", "conv_halo_cv1_kernel: bottleneck 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
+    ("stream_resident", "conv_stream_kernel: 1x1 (and narrow 3x3), weights resident in LDS", lambda v: 2000 <= v < 3000),
+    ("stream_ring", "conv_stream_kernel: large-K 1x1, weight ring", lambda v: 3000 <= v < 4000),
+    ("tile", "conv_igemm_kernel: detection levels (N = 45) + fallback shapes", lambda v: 1000 <= v < 2000),
+]
+
+
+def family_of(tag):
+    if tag // 10000 != 2:
+        return "non_conv"
+    v = tag % 10000
+    for name, _, pred in FAMILIES:
+        if pred(v):
+            return name
+    return "conv_other"
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_workers(a)
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or run "
+                         f"`python bench.py --gpus {a.gpus}` and let it spawn the workers)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the SkyEye engine has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     from skyeye.utils.metrics import nms_raw
+    from skyeye.utils.torch_utils import capture_graph
     from skyeye.distributed import all_gather_detections
 
     model, P = build_model(a.model, a.precision, dev)
     B, S = a.batch, a.size
     frames_np = np.random.default_rng(rank).integers(0, 256, size=(B, 3, S, S), dtype=np.uint8)
     x = torch.from_numpy(frames_np).to(dev)
+    if a.precision == "fp8":
+        model.calibrate(x[:2])                               # per-tensor activation scales from two frames of the workload
     shift = calibrate_objectness(model, x, 0.01, a.conf)
+    model.reuse_output_buffers(True)
+
+    def local_step():
+        det, _raw = model(x, return_raw=a.with_raw)                             # detector.py:300-324
+        return nms_raw(det, a.conf, a.iou, max_detections=300)                  # metrics.py:361-457, no host sync
+
+    graph = None
+    if not a.no_graph:
+        graph, held = capture_graph(local_step, warmup=2)                       # static shapes: one hipGraph replay per step
 
     def step():
-        det, _raw = model(x)                                                    # detector.py:300-324
-        rows, counts = nms_raw(det, a.conf, a.iou, max_detections=300)          # metrics.py:361-457, no host sync
+        if graph is not None:
+            graph.replay()
+            rows, counts = held
+        else:
+            rows, counts = local_step()
         if world > 1:
             rows, counts = all_gather_detections(rows, counts)                  # RCCL over xGMI
         return rows, counts
@@ -134,6 +216,26 @@ def main():
         lat.append((time.perf_counter() - t1) * 1e3)
     lat.sort()
 
+    # the three timing buckets the reference's CLIs print (validate.py:323-326): pre-process / inference / NMS, ms per image.
+    # Pre-process there is .to(device).float() / 255 (validate.py:236-238): here the uint8 frames are already in HBM and the
+    # conversion + /255 are fused into the stem's loader, so the bucket is empty by construction.
+    def timed(fn, n=10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+    det_keep, _ = model(x, return_raw=a.with_raw)
+    det_keep = det_keep.clone()
+    inf_ms = timed(lambda: model(x, return_raw=a.with_raw))
+    nms_ms = timed(lambda: nms_raw(det_keep, a.conf, a.iou, max_detections=300))
+    # worst-case NMS leg: validate.py:117's conf 0.001 drives every image into the 30 000-candidate cap (metrics.py:393)
+    worst_ms = timed(lambda: nms_raw(det_keep, 0.001, a.iou, max_detections=300), n=5)
+    n_cand = int((det_keep[..., 4] > 0.001).sum(1).float().mean().item())
+
     frames = world * B * a.steps
     fps = frames / dt
     out = {
@@ -142,11 +244,17 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "p50_latency_ms": round(lat[len(lat) // 2], 3), "p99_latency_ms": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 3),
+        "rccl_ranks_seen": ranks_seen,
+        "buckets_ms_per_image": {"pre_process": 0.0, "inference": round(inf_ms / B, 4), "nms": round(nms_ms / B, 4),
+                                 "note": "validate.py:323-326 buckets; pre-process (uint8 -> float, /255) is fused into the stem's loader"},
+        "nms_worst_case": {"conf": 0.001, "ms_per_batch": round(worst_ms, 3), "ms_per_image": round(worst_ms / B, 4),
+                           "mean_candidates_per_image": n_cand, "cap": 30000},
         "config": {"workload": f"{a.model} {a.precision} batch={B}/GPU @{S}x{S}: uint8 frames in HBM -> backbone+neck+heads+"
                                f"decode -> NMS(conf {a.conf}, iou {a.iou}, max_det 300)"
                                + (" -> RCCL all-gather of boxes" if world > 1 else ""),
                    "global_batch": world * B, "frames_per_gpu": B, "image_size": S, "candidates_target": "1% > conf",
-                   "mean_boxes_kept_per_image": round(kept_mean, 1), "parallelism": f"dp{world} (independent images)"},
+                   "mean_boxes_kept_per_image": round(kept_mean, 1), "parallelism": f"dp{world} (independent images)",
+                   "hip_graph": graph is not None, "raw_levels_written": bool(a.with_raw)},
     }
 
     if rank == 0 and not a.no_roofline:
@@ -155,52 +263,49 @@ def main():
         outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in h.output_shapes()]
         stream = torch.cuda.current_stream(dev).cuda_stream
         prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], stream, iters=3)
-        by = {}
+        fam = {}
         for i, (ms, fl, tag) in enumerate(prof):
-            e = by.setdefault(tag, [0.0, 0.0, 0, 0.0])
-            e[0] += ms; e[1] += fl; e[2] += 1; e[3] += h.op_bytes(i)
-        conv = {t: v for t, v in by.items() if t // 10000 == 2}      # OP_CONV
-        dom_tag, dom = max(conv.items(), key=lambda kv: kv[1][0])
-        variant = dom_tag % 10000
-        tname = "bf16" if a.precision == "bf16" else "float"
-        kname = (f"conv_halo_kernel<{tname}> stride-2 halo tile + weight ring, N_blk {variant % 1000}" if variant >= 6000 else
-                 f"conv_halo_small_kernel<{tname}> narrow-input halo tile, N_blk {variant % 1000}" if variant >= 5000 else
-                 f"conv_halo_kernel<{tname}> halo tile + weight ring, N_blk {variant % 1000}" if variant >= 4000 else
-                 f"conv_stream_kernel<{tname}> weight-ring, N_blk {variant % 1000}" if variant >= 3000 else
-                 f"conv_stream_kernel<{tname}> resident weights, N_blk {variant % 1000}" if variant >= 2000 else
-                 f"conv_igemm_kernel<{tname}> N tile {variant % 1000}")
-        conv_ms = sum(v[0] for v in conv.values()); conv_fl = sum(v[1] for v in conv.values())
-        tot_ms = sum(v[0] for v in by.values())
+            e = fam.setdefault(family_of(tag), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, variants=set()))
+            e["launches"] += 1; e["ms"] += ms; e["flops"] += fl; e["bytes"] += h.op_bytes(i)
+            if tag // 10000 == 2:
+                e["variants"].add(tag % 10000)
         peak = PEAK_TFLOPS[a.precision]
-        ach = dom[1] / (dom[0] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):     # latest PMC pass (tools/pmc_traffic.sh)
-            try:
-                tv = json.load(open(f))["by_variant"].get(str(variant))
-                if tv and a.model == "skyeye_s" and B == 32 and S == 1280 and a.precision == "bf16":
-                    traffic, traffic_src = round(tv["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
-            except Exception:  # noqa: BLE001
-                pass
-        hbm_gbps = dom[3] / (dom[0] * 1e-3) / 1e9                         # algorithmic in+out(+residual) bytes per launch / time
-        frac_mfma, frac_hbm = ach / peak, hbm_gbps / PEAK_HBM_GBPS
-        hbm_bound = frac_hbm > frac_mfma                                   # report the roof this kernel group is closer to
+        pmc, pmc_src = {}, None
+        if a.model == "skyeye_s" and B == 32 and S == 1280 and a.precision == "bf16":
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):     # latest PMC pass (tools/pmc_traffic.sh)
+                try:
+                    pmc, pmc_src = json.load(open(f))["by_variant"], os.path.relpath(f, ROOT)
+                except Exception:  # noqa: BLE001
+                    pass
+        table = {}
+        for name, e in fam.items():
+            t = e["ms"] * 1e-3
+            pb = [pmc[str(v)]["hbm_bytes_per_launch"] * 1.0 for v in e["variants"] if str(v) in pmc]
+            table[name] = {"launches": e["launches"], "ms": round(e["ms"], 4), "avg_launch_ms": round(e["ms"] / e["launches"], 4),
+                           "tflops": round(e["flops"] / t / 1e12, 1) if t else 0.0, "frac_mfma": round(e["flops"] / t / 1e12 / peak, 4) if t else 0.0,
+                           "algorithmic_gbps": round(e["bytes"] / t / 1e9, 1) if t else 0.0,
+                           "frac_hbm": round(e["bytes"] / t / 1e9 / PEAK_HBM_GBPS, 4) if t else 0.0,
+                           "algorithmic_bytes_per_launch": round(e["bytes"] / e["launches"]),
+                           "pmc_bytes_per_launch": round(sum(pb) / len(pb)) if pb else None}
+        desc = {n: k for n, k, _ in FAMILIES}
+        conv_names = [n for n in table if n not in ("non_conv",)]
+        dom = max(conv_names, key=lambda n: table[n]["ms"])
+        graph_flops = sum(e["flops"] for e in fam.values())
+        graph_bytes = sum(e["bytes"] for e in fam.values())
+        tot_ms = sum(e["ms"] for e in fam.values())
+        e2e_tflops = fps / world * graph_flops / B / 1e12
         out["roofline"] = {
-            "bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
-            "achieved": round(hbm_gbps if hbm_bound else ach, 2), "peak": PEAK_HBM_GBPS if hbm_bound else peak,
-            "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(max(frac_hbm, frac_mfma), 4), "traffic": traffic,
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dom[3] / dom[2]),
-            "hbm_gbps_algorithmic": round(hbm_gbps, 1), "frac_hbm": round(frac_hbm, 4),
-            "tflops": round(ach, 2), "frac_mfma": round(frac_mfma, 4),
-            "launches_per_step": dom[2], "avg_launch_ms": round(dom[0] / dom[2], 4),
-            "flops_per_launch": dom[1] / dom[2],
-            "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "conv_ms_per_step": round(conv_ms, 3),
+            "bound": "mfma", "achieved": round(e2e_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(e2e_tflops / peak, 4),
+            "definition": "end-to-end: frames/s per GPU x algorithmic GFLOP/frame (2*MAC over conv/linear) / dense MFMA peak",
+            "traffic": round(sum(v["pmc_bytes_per_launch"] * v["launches"] for v in table.values() if v["pmc_bytes_per_launch"])) or None,
+            "traffic_source": pmc_src, "traffic_note": "PMC bytes per step summed over the convolution families (FETCH_SIZE x2 + WRITE_SIZE)",
+            "graph_gflop_per_frame": round(graph_flops / B / 1e9, 2), "baseline_gflop_per_frame": GFLOP_PER_FRAME.get((a.model, S)),
+            "algorithmic_bytes_per_step": round(graph_bytes), "end_to_end_hbm_gbps": round(fps / world / B * graph_bytes / 1e9, 1),
+            "end_to_end_frac_hbm": round(fps / world / B * graph_bytes / 1e9 / PEAK_HBM_GBPS, 4),
             "graph_ms_per_step": round(tot_ms, 3), "graph_launches": len(prof),
-            "conv_variants": {str(t % 10000): {"launches": v[2], "ms": round(v[0], 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
-                              for t, v in sorted(conv.items())},
-            "graph_gflop_per_frame": round(sum(v[1] for v in by.values()) / B / 1e9, 2),
-            "baseline_gflop_per_frame": GFLOP_PER_FRAME.get((a.model, S)),
-            "end_to_end_tflops": round(fps / world * sum(v[1] for v in by.values()) / B / 1e12, 2),
+            "dominant": dict(family=dom, kernel=desc.get(dom, dom), **table[dom]),
+            "families": table,
         }
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -226,7 +331,9 @@ def main():
         cpu_dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(n / cpu_dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port",
                                "sample": f"{n} frame(s) of the same workload ({a.model} fp32 @{S}x{S}, forward+decode+NMS), "
-                                         f"oracle/ C+OpenMP port, {os.cpu_count()} host CPUs visible"}
+                                         f"oracle/ C+OpenMP port of the reference path, {O.threads()} threads used of {os.cpu_count()} host "
+                                         "CPUs visible; the reference's own PyTorch-CPU path measured ~1.09 frames/s on 8 cores at "
+                                         "survey time (BASELINE.md section 2) -- a reported baseline, not the target"}
 
     if rank == 0:
         print(json.dumps(out))

@@ -143,7 +143,9 @@ typedef struct {
     int32_t max_detections;     /* 300 */
     int32_t max_nms;            /* 30000, metrics.py:393 */
     float max_wh;               /* 4096, metrics.py:392 */
-    int32_t mode;               /* 0 = literal (file as written, D7-D9), 1 = corrected (YOLOv5 semantics) */
+    int32_t mode;               /* 0 = literal (file as written, D7-D9), 1 = corrected (YOLOv5 semantics), 2 = box rows: `det` rows
+                                 * are already boxes (x1, y1, x2, y2, conf, cls, ...; row stride nc + 5 floats) -- the cross-tile
+                                 * stage of tiled inference, whose input is the survivors of the per-tile NMS */
     int32_t n_classes;          /* length of `classes`, 0 = no filter */
     int32_t classes[64];
 } sky_nms_params;
@@ -230,6 +232,14 @@ int sky_scale_img(sky_handle* h, const void* src, int src_dtype, int B, int C, i
  * origins != NULL (device int32 [B, 2] = (y, x) of each tile), cx += x, cy += y.  Other columns are copied. */
 int sky_map_detections(sky_handle* h, const float* src, int B, int N, int no, int row0, int rows, float scale, int flip, float img_h, float img_w,
                        const int32_t* origins, int tiles_per_image, float* dst, int64_t dst_rows, int64_t dst_row0, void* stream);
+
+/* Tiled inference across ranks ("Tiled (C5)"; build-defined, the reference has no tiling): the survivors of the per-tile
+ * NMS -- rows [T, R, cols] fp32 on the device, corner boxes (x1, y1, x2, y2, ...) in tile pixels, counts[T] valid rows per tile -- are
+ * moved in place into the frame of the whole image: x += origins[t][1], y += origins[t][0] (device int32 [T, 2] = (y, x)); rows past
+ * counts[t] are left untouched.  The collective that follows (all-gather of these fixed-capacity blocks over RCCL) belongs to the host
+ * layer, skyeye/distributed.py: this library exports no collective of its own (one process per GPU owns its communicator); the
+ * owner rank then calls sky_nms with mode = 2 on the gathered rows. */
+int sky_offset_boxes(sky_handle* h, float* rows, const int32_t* counts, int T, int R, int cols, const int32_t* origins, void* stream);
 
 /* Large-frame tiling: src uint8 [H0, W0, 3] (src_chw = 0) or [3, H0, W0] (src_chw = 1) on the device -> dst uint8 [n, 3, tile_h, tile_w],
  * tile t = the window at origins[t] = (y, x) (device int32 [n, 2]); pixels outside the frame = pad_value (114);

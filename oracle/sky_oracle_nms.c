@@ -27,6 +27,9 @@
  * mode 1 ("corrected") = the YOLOv5 semantics the reference imitates:
  *     conf = obj*cls, boxes converted to corners, offset = class id * 4096,
  *     rows [x1,y1,x2,y2,conf,cls].  Build-defined, no reference counterpart.
+ * mode 2 ("rows") = the input rows are already boxes (x1,y1,x2,y2,conf,cls,...;
+ *     stride nc+5): the cross-tile stage of tiled inference over the survivors of
+ *     the per-tile NMS.  Build-defined, no reference counterpart.
  *
  * Compile with -ffp-contract=off: every product and sum must round exactly as
  * the fp32 tensor ops of the reference do.
@@ -80,6 +83,10 @@ int sky_oracle_nms_image(const float* pred, int n, int nc, float conf_thres, flo
     for (int i = 0; i < n; ++i) {
         const float* p = pred + (size_t)i * no;
         if (!(p[4] > conf_thres)) continue;                      /* metrics.py:389,402 */
+        if (mode == 2) {
+            PUSH(p[0], p[1], p[2], p[3], p[4], p[5], 0.0f);
+            continue;
+        }
         if (mode == 0) {
             if (nc > 1) {
                 if (multi_label) {                               /* metrics.py:412-413 */

@@ -382,7 +382,7 @@ def non_max_suppression(prediction, conf_threshold=0.25, iou_threshold=0.45, cla
             _p(pred[b]), N, nc, ctypes.c_float(conf_threshold), ctypes.c_float(iou_threshold),
             None if cls is None else cls.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 0 if cls is None else len(cls),
             int(bool(agnostic)), int(bool(multi_label)), int(max_detections), 30000, ctypes.c_float(4096.0),
-            0 if mode == "literal" else 1, _p(buf), ctypes.byref(cols))
+            {"literal": 0, "corrected": 1, "rows": 2}[mode], _p(buf), ctypes.byref(cols))
         c = cols.value
         out.append(buf.reshape(-1)[: n * c].reshape(n, c).copy() if n else np.zeros((0, 6), np.float32))
     return out

@@ -143,6 +143,8 @@ struct Engine {
     // nms workspace
     void* nms_ws = nullptr;
     size_t nms_ws_bytes = 0;
+    unsigned opts = 0;      // PlanOpt bits, read from the environment once per sky_plan
+    int n_cu = 256;         // compute units of cfg.device
 
     int esize() const { return dtype == SKY_F32 ? 4 : 2; }
     int epc() const { return dtype == SKY_F32 ? 4 : 8; }
@@ -239,7 +241,7 @@ struct Ctx {
         if (!emit) return;
         // opt-in (SKY_FUSE=1): measured neutral on MI355X -- the producer's epilogue is VALU-bound, the second GEMM and
         // its epilogue cost what the separate 1x1 launch costs
-        const bool no_fuse = getenv("SKY_FUSE") == nullptr || getenv("SKY_NO_FUSE") != nullptr;
+        const bool no_fuse = !(e.opts & OPT_FUSE);
         if (!no_fuse && !e.ops.empty() && op.kind == OP_CONV) {
             Op& a = e.ops.back();
             const long koff = op.in.off - a.out.off;
@@ -444,7 +446,7 @@ static TV spp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, cons
     o1.out_into = &s0;
     conv_block(c, p + "cv1.", x, cin, h, 1, 1, true, o1);
     // small maps (the 40 x 40 of a 1280-pixel frame): the three cascaded pools in one launch that reads cv1's slice once
-    static const bool no_pyramid = getenv("SKY_NO_SPP_PYRAMID") != nullptr;
+    const bool no_pyramid = (c.e.opts & OPT_NO_SPP_PYRAMID) != 0;
     const int vec = c.e.dtype == 0 ? 4 : 8;
     if (!no_pyramid && h % (2 * vec) == 0 && (long)x.H * x.W * 2 <= 4096) {
         Op op;
@@ -1115,6 +1117,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         t.B = nx.in.B; t.H = nx.in.H; t.W = nx.in.W; t.Cin = nx.cin; t.ldi = nx.in.ld; t.Ho = nx.Ho; t.Wo = nx.Wo; t.Cout = nx.cout;
                         t.ldo = nx.out.ld; t.ks = 3; t.stride = 1; t.pad = 1; t.Kpad = e.convs[nx.wid].Kpad; t.up2 = nx.up2; t.head = nx.head;
                         t.M = nx.in.B * nx.Ho * nx.Wo;
+                        t.opts = e.opts; t.device = cf.device; t.n_cu = e.n_cu;
                         const double oext = (((double)t.M - 1.0) * nx.out.ld + nx.cout) * e.esize();
                         t.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
                         if (conv_accepts_raw(e.dtype, t)) {
@@ -1140,6 +1143,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 a.in = tv_ptr(e, op.in, ins, n_in, outs, n_out);
                 if (raw_src) { a.in = raw_src; a.src_mode = raw_mode; raw_src = nullptr; }
                 a.w = d.w; a.bias = d.bias; a.Kpad = d.Kpad; a.zero = e.zero_page;
+                a.opts = e.opts; a.device = cf.device; a.n_cu = e.n_cu;
                 a.B = op.in.B; a.H = op.in.H; a.W = op.in.W; a.Cin = op.cin; a.ldi = op.in.ld;
                 a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.cout;
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.ks / 2;
@@ -1153,7 +1157,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     a.head = 1;
                     TV r; r.ext = op.raw_ext;
                     TV dt; dt.ext = op.det_ext;
-                    a.raw = (float*)tv_ptr(e, r, ins, n_in, outs, n_out);
+                    a.raw = (float*)tv_ptr(e, r, ins, n_in, outs, n_out);       // may be NULL: the caller does not want the raw level
                     a.det = (float*)tv_ptr(e, dt, ins, n_in, outs, n_out);
                     a.na = cf.num_anchors; a.no = cf.nc + 5;
                     a.det_rows = op.det_rows; a.det_off = op.det_off; a.stride_px = op.stride_px;
@@ -1223,7 +1227,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 SKY_HIP(launch_attention(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                          op.out.ld, op.win ? op.in.B * (op.in.H / op.win) * (op.in.W / op.win) : op.in.B, op.ntok, op.out.C, op.heads,
                                          op.scale, op.f0 >= 0 ? e.fweights[op.f0] : nullptr,
-                                         op.mask_ext >= 0 ? (const float*)ins[op.mask_ext].data : nullptr, op.nW, op.win, op.in.H, op.in.W, s));
+                                         op.mask_ext >= 0 ? (const float*)ins[op.mask_ext].data : nullptr, op.nW, op.win, op.in.H, op.in.W, s, e.opts));
                 break;
             case OP_CLA:
                 SKY_HIP(launch_cla(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.in2, ins, n_in, outs, n_out),
@@ -1290,9 +1294,48 @@ static void collect_spec(Engine& e)
     build(c, g);
 }
 
+// The developer switches of sky_kernels.h (PlanOpt), read from the environment once per plan.
+static unsigned read_plan_opts()
+{
+    unsigned o = 0;
+    auto env = [](const char* k) { return getenv(k); };
+    if (const char* v = env("SKY_CONV_HALO")) o |= v[0] == '0' ? OPT_HALO_OFF : v[0] == 'f' ? OPT_HALO_FORCE : 0u;
+    if (const char* v = env("SKY_HALO_NF8")) o |= v[0] == 'o' ? OPT_NF8_OFF : v[0] == 's' ? OPT_NF8_SOLO : 0u;
+    if (const char* v = env("SKY_HALO_S2")) o |= v[0] == '0' ? OPT_S2_OFF : 0u;
+    if (env("SKY_NO_STREAM")) o |= OPT_NO_STREAM;
+    if (env("SKY_NO_RING")) o |= OPT_NO_RING;
+    if (env("SKY_STREAM_OLDGRID")) o |= OPT_OLDGRID;
+    if (env("SKY_NO_FUSED_IMPORT")) o |= OPT_NO_FUSED_IMPORT;
+    if (env("SKY_FUSE") && !env("SKY_NO_FUSE")) o |= OPT_FUSE;
+    if (env("SKY_NO_SPP_PYRAMID")) o |= OPT_NO_SPP_PYRAMID;
+    if (env("SKY_ATTN_VALU")) o |= OPT_ATTN_VALU;
+    if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
+    return o;
+}
+
+// Every entry point that launches work runs on the handle's own device, whatever the caller's current device is.
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) SKY_HIP(hipSetDevice(dev));
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
 static void plan(Engine& e, const Geometry& g)
 {
     e.free_plan();
+    e.opts = read_plan_opts();
+    {
+        hipDeviceProp_t prop;
+        SKY_HIP(hipGetDeviceProperties(&prop, e.cfg.device));
+        e.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     e.flops = e.act_bytes = e.weight_bytes = 0;
     e.out_info.clear();
     e.spec.clear();
@@ -1413,7 +1456,7 @@ int sky_plan(sky_handle* h, int n_inputs, const sky_buffer* in)
         if (n_inputs < 1 || n_inputs > SKY_MAX_IO) throw Error(SKY_ERR_INVALID, "sky_plan: bad input count");
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(SKY_ERR_NO_DEVICE, "no HIP device visible: the HIP engine cannot run (there is no CPU fallback)");
-        SKY_HIP(hipSetDevice(h->e.cfg.device));
+        DeviceGuard dg(h->e.cfg.device);
         Geometry g;
         g.n = n_inputs;
         for (int i = 0; i < n_inputs; ++i) {
@@ -1448,8 +1491,12 @@ static void check_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs,
         for (int k = 0; k < h->geom.ndim[i]; ++k)
             if (inputs[i].shape[k] != h->geom.shape[i][k]) throw Error(SKY_ERR_SHAPE, "sky_forward: input shape differs from the plan");
     }
+    // raw detection levels are optional (NULL = not wanted: the head epilogue then skips their stores); everything else is required
+    std::vector<char> optional(n_outputs, 0);
+    for (const Op& op : h->e.ops)
+        if (op.kind == OP_CONV && op.head && op.raw_ext >= 16 && op.raw_ext - 16 < n_outputs) optional[op.raw_ext - 16] = 1;
     for (int i = 0; i < n_outputs; ++i)
-        if (!outputs[i].data) throw Error(SKY_ERR_INVALID, "sky_forward: null output");
+        if (!outputs[i].data && !optional[i]) throw Error(SKY_ERR_INVALID, "sky_forward: null output");
 }
 
 int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs, void* stream)
@@ -1457,6 +1504,7 @@ int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_out
     if (!h) return SKY_ERR_INVALID;
     return guarded(h, [&] {
         check_forward(h, n_inputs, inputs, n_outputs, outputs);
+        DeviceGuard dg(h->e.cfg.device);
         run(h->e, inputs, n_inputs, outputs, n_outputs, (hipStream_t)stream);
     });
 }
@@ -1467,6 +1515,7 @@ int sky_time_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int 
     if (!h) return SKY_ERR_INVALID;
     return guarded(h, [&] {
         check_forward(h, n_inputs, inputs, n_outputs, outputs);
+        DeviceGuard dg(h->e.cfg.device);
         hipStream_t s = (hipStream_t)stream;
         hipEvent_t e0, e1;
         SKY_HIP(hipEventCreate(&e0));
@@ -1489,6 +1538,7 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
     if (!h) return SKY_ERR_INVALID;
     return guarded(h, [&] {
         check_forward(h, n_inputs, inputs, n_outputs, outputs);
+        DeviceGuard dg(h->e.cfg.device);
         const int n = (int)h->e.ops.size();
         if (n_ops) *n_ops = n;
         if (n > max_ops) throw Error(SKY_ERR_INVALID, "sky_profile_forward: max_ops too small");
@@ -1526,6 +1576,10 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
                  op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
+    if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)
+        const size_t n = strlen(text);
+        if ((int)n + 16 < text_len) snprintf(text + n, text_len - n, " opts=0x%x", h->e.opts);
+    }
     return SKY_OK;
 }
 
@@ -1576,6 +1630,7 @@ int sky_packed_read(sky_handle* h, int i, void* weights_host, size_t weight_byte
     if (!h) return SKY_ERR_INVALID;
     return guarded(h, [&] {
         if (!h->e.planned) throw Error(SKY_ERR_STATE, "sky_packed_read: plan the graph first (weights are packed at plan time)");
+        DeviceGuard dg(h->e.cfg.device);
         if (i < 0 || i >= (int)h->e.convs.size()) throw Error(SKY_ERR_INVALID, "sky_packed_read: index out of range");
         const DevConv& d = h->e.convs[i];
         if (weights_host) {
@@ -1598,12 +1653,15 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
         if (B < 1 || N < 1 || nc < 1) throw Error(SKY_ERR_SHAPE, "sky_nms: bad geometry");
         if (p->max_detections < 1 || p->max_detections > 4096) throw Error(SKY_ERR_INVALID, "sky_nms: max_detections must be in [1, 4096]");
         if (p->n_classes > 64) throw Error(SKY_ERR_INVALID, "sky_nms: at most 64 class filters");
+        DeviceGuard dg(h->e.cfg.device);
         NmsArgs a;
         memset(&a, 0, sizeof(a));
+        a.device = h->e.cfg.device;
         a.det = det; a.B = B; a.N = N; a.nc = nc;
         a.conf = p->conf_threshold; a.iou = p->iou_threshold; a.max_wh = p->max_wh;
         a.agnostic = p->agnostic; a.max_det = p->max_detections; a.max_nms = p->max_nms; a.mode = p->mode;
-        a.multi_label = p->multi_label && nc > 1;       // metrics.py:396
+        if (p->mode < 0 || p->mode > 2) throw Error(SKY_ERR_INVALID, "sky_nms: mode is 0 (literal), 1 (corrected) or 2 (box rows)");
+        a.multi_label = p->multi_label && nc > 1 && p->mode != 2;       // metrics.py:396
         a.n_classes = p->n_classes;
         for (int i = 0; i < p->n_classes; ++i) a.classes[i] = p->classes[i];
         a.out = out; a.counts = counts;
@@ -1632,6 +1690,7 @@ int sky_box_iou(sky_handle* h, const float* box1, int n, int box1_is_4xn, const 
     return guarded(h, [&] {
         if (n < 0 || m < 0) throw Error(SKY_ERR_SHAPE, "sky_box_iou: negative box count");
         if ((n && !box1) || (m && !box2) || ((long)n * m && !out)) throw Error(SKY_ERR_INVALID, "sky_box_iou: null argument");
+        DeviceGuard dg(h->e.cfg.device);
         SKY_HIP(launch_box_iou(box1, n, box1_is_4xn ? 1 : 0, box2, m, out, (hipStream_t)stream));
     });
 }
@@ -1644,6 +1703,7 @@ int sky_letterbox(sky_handle* h, const uint8_t* src, int H0, int W0, uint8_t* ds
         if (!src || !dst) throw Error(SKY_ERR_INVALID, "sky_letterbox: null argument");
         if (H0 < 1 || W0 < 1 || new_h < 1 || new_w < 1 || top < 0 || left < 0 || top + new_h > H1 || left + new_w > W1)
             throw Error(SKY_ERR_SHAPE, "sky_letterbox: the resized frame plus its border must fit the destination");
+        DeviceGuard dg(h->e.cfg.device);
         SKY_HIP(launch_letterbox(src, H0, W0, dst, H1, W1, new_h, new_w, top, left, pad_value & 255, dst_chw ? 1 : 0, reverse_channels ? 1 : 0,
                                  (hipStream_t)stream));
     });
@@ -1659,6 +1719,7 @@ int sky_scale_img(sky_handle* h, const void* src, int src_dtype, int B, int C, i
         if (flip != 0 && flip != 2 && flip != 3) throw Error(SKY_ERR_INVALID, "sky_scale_img: flip is 0, 2 (rows) or 3 (columns)");
         if (B < 1 || C < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1 || pad_h < out_h || pad_w < out_w)
             throw Error(SKY_ERR_SHAPE, "sky_scale_img: the resized image must be non-empty and fit the padded destination");
+        DeviceGuard dg(h->e.cfg.device);
         SKY_HIP(launch_scale_img(src, src_dtype == SKY_IO_U8, B * C, H, W, dst, out_h, out_w, pad_h, pad_w, flip, pad_value, (hipStream_t)stream));
     });
 }
@@ -1675,8 +1736,20 @@ int sky_map_detections(sky_handle* h, const float* src, int B, int N, int no, in
             dst_row0 + (int64_t)tiles_per_image * rows > dst_rows)
             throw Error(SKY_ERR_SHAPE, "sky_map_detections: source rows [row0, row0 + rows) of every tile must fit the destination image");
         if (rows == 0) return;
+        DeviceGuard dg(h->e.cfg.device);
         SKY_HIP(launch_map_detections(src, B, N, no, row0, rows, scale, flip, img_h, img_w, origins, tiles_per_image, dst, (long)dst_rows,
                                       (long)dst_row0, (hipStream_t)stream));
+    });
+}
+
+int sky_offset_boxes(sky_handle* h, float* rows, const int32_t* counts, int T, int R, int cols, const int32_t* origins, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!rows || !counts || !origins) throw Error(SKY_ERR_INVALID, "sky_offset_boxes: null argument");
+        if (T < 0 || R < 1 || cols < 4) throw Error(SKY_ERR_SHAPE, "sky_offset_boxes: rows must be [T, R, cols >= 4]");
+        DeviceGuard dg(h->e.cfg.device);
+        SKY_HIP(launch_offset_boxes(rows, counts, T, R, cols, origins, (hipStream_t)stream));
     });
 }
 
@@ -1687,6 +1760,7 @@ int sky_tile_gather(sky_handle* h, const uint8_t* src, int H0, int W0, int src_c
     return guarded(h, [&] {
         if (!src || !dst || !origins) throw Error(SKY_ERR_INVALID, "sky_tile_gather: null argument");
         if (H0 < 1 || W0 < 1 || n < 1 || tile_h < 1 || tile_w < 1) throw Error(SKY_ERR_SHAPE, "sky_tile_gather: empty frame or tile");
+        DeviceGuard dg(h->e.cfg.device);
         SKY_HIP(launch_tile_gather(src, H0, W0, src_chw ? 1 : 0, origins, n, dst, tile_h, tile_w, pad_value & 255, reverse_channels ? 1 : 0,
                                    (hipStream_t)stream));
     });
@@ -1696,6 +1770,7 @@ int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* coun
 {
     if (!h) return SKY_ERR_INVALID;
     return guarded(h, [&] {
+        DeviceGuard dg(h->e.cfg.device);
         SKY_HIP(hipMemcpyAsync(counts_host, counts_dev, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
         SKY_HIP(hipStreamSynchronize((hipStream_t)stream));
     });

@@ -300,10 +300,10 @@ static hipError_t attention_t(const void* qkv, int ldq, void* out, int ldo, int 
 }
 
 hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale,
-                            const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s)
+                            const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s, unsigned opts)
 {
     const int D = heads > 0 ? C / heads : 0;
-    const bool no_mfma = getenv("SKY_ATTN_VALU") != nullptr;              // A/B switch (read per launch: tests toggle it)
+    const bool no_mfma = (opts & OPT_ATTN_VALU) != 0;                     // A/B switch, fixed at plan time
     if (dtype != 0 && !no_mfma && N >= 64 && (D == 32 || D == 64 || D == 128) && ldq % 8 == 0 && ldo % 4 == 0 && C % 8 == 0) {
         const dim3 grid((N + 63) / 64, heads, G);
         const bool win = ws > 0 || bias || mask;

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
                             dv4[e] = dv;
                         }
                         const int o0 = r0 - ml0 * a.no;
-                        *reinterpret_cast<f32x4_t*>(a.raw + (long)(c0 + an * HoWo) * a.no + o0) = rv4;
+                        if (a.raw) *reinterpret_cast<f32x4_t*>(a.raw + (long)(c0 + an * HoWo) * a.no + o0) = rv4;
                         *reinterpret_cast<f32x4_t*>(a.det + (long)(rowb[BM + ml0] + an * HoWo) * a.no + o0) = dv4;
                     } else {
                         for (int e = 0; e < 4; ++e) {
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
                             if (rowb[ml] < 0) continue;
                             float rv, dv;
                             element(an, ml, o, aw, ah, rv, dv);
-                            a.raw[(long)(rowb[ml] + an * HoWo) * a.no + o] = rv;
+                            if (a.raw) a.raw[(long)(rowb[ml] + an * HoWo) * a.no + o] = rv;
                             a.det[(long)(rowb[BM + ml] + an * HoWo) * a.no + o] = dv;
                         }
                     }
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
                 if (rowb[ml] < 0) continue;
                 float rv, dv;
                 element(an, ml, o, aw, ah, rv, dv);
-                a.raw[(long)(rowb[ml] + an * HoWo) * a.no + o] = rv;
+                if (a.raw) a.raw[(long)(rowb[ml] + an * HoWo) * a.no + o] = rv;
                 a.det[(long)(rowb[BM + ml] + an * HoWo) * a.no + o] = dv;
             }
         }
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             const int y = t % a.Ho;
             const int b = t / a.Ho;
             const long cell = ((long)(b * a.na + an) * a.Ho + y) * a.Wo + x;
-            a.raw[cell * a.no + o] = v;
+            if (a.raw) a.raw[cell * a.no + o] = v;
             const float s = head_sigmoid<sizeof(T) == 2>(v);
             float d;
             if (o == 0) d = (s * 2.0f - 0.5f + (float)x) * a.stride_px;
@@ -425,12 +425,11 @@ static hipError_t launch_one(const ConvArgs& a, hipStream_t s)
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
     constexpr size_t epi = BM * (BN + 4) * 4 + 4 * BM * 4;   // epilogue tile + per-pixel head tables
     constexpr size_t lds = (2 * (BM + BN) * 128 > epi) ? 2 * (BM + BN) * 128 : epi;
-    static bool attr_set = false;
+    static size_t attr[16] = {0};
     auto kern = conv_igemm_kernel<T, WM, WN, MF, NF>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     ConvArgs b = a;
     b.ntiles = (a.Cout + BN - 1) / BN;
@@ -454,8 +453,7 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
     if (fused) *fused = 0;
-    static const bool no_stream = getenv("SKY_NO_STREAM") != nullptr;   // A/B switch for profiling
-    if (!no_stream) {
+    if (!(a.opts & OPT_NO_STREAM)) {   // A/B switch for profiling
         const hipError_t eh = launch_conv_halo(dtype, a, s, variant, fused);
         if (eh != hipErrorNotSupported) return eh;
         const hipError_t e = launch_conv_stream(dtype, a, s, variant, fused);

@@ -29,6 +29,14 @@
 
 #include "conv_frag.h"
 
+// Kernel experiments (stage switches, clock stamps, LDS padding) exist only in builds with -DSKY_EXPERIMENTS: the shipped
+// library has no code path that skips work, whatever SKY_CONV_DBG says (tests/test_gpu_conv_halo.py checks that).
+#ifdef SKY_EXPERIMENTS
+#define SKY_DBG(a) ((a).dbg)
+#else
+#define SKY_DBG(a) 0
+#endif
+
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -49,7 +57,7 @@ __device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F7
 // experiment (SKY_CONV_DBG & 256): shader-clock stamps of one wave's second tile, kept in LDS, dumped at kernel end
 __device__ __forceinline__ void dbg_stamp(const ConvArgs& a, unsigned long long* st, int nth_tile, int slot)
 {
-    if ((a.dbg & 256) && nth_tile == 1 && threadIdx.x == 0) st[slot] = __builtin_amdgcn_s_memtime();
+    if ((SKY_DBG(a) & 256) && nth_tile == 1 && threadIdx.x == 0) st[slot] = __builtin_amdgcn_s_memtime();
 }
 // 16 bytes per lane: global (buffer rsrc, per-lane byte offset voff + uniform soff) -> LDS at `dst` + lane * 16
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst, int voff, int soff)
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     constexpr int WSLAB = NB * 128;               // bytes of one weight slab
     constexpr int WDMA = NB / 8 / HWV;            // weight DMA instructions per wave per slab (8 rows each)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* const halo = smem + (((a.dbg >> 16) & 0xff) << 10);      // experiment: SKY_CONV_DBG bits 16..23 = KB of padding in front
+    char* const halo = smem + (((SKY_DBG(a) >> 16) & 0xff) << 10);      // experiment: SKY_CONV_DBG bits 16..23 = KB of padding in front
     char* const wring = halo + HALO_BYTES;
     float* const lbias = reinterpret_cast<float*>(halo + HALO_BYTES + 2 * WSLAB);
     char* const w2lds = halo + HALO_BYTES + 2 * WSLAB + NB * 4;                   // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
@@ -358,8 +366,8 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     const TapStep first = tap_step<S2>(0);
     __syncthreads();                                   // bias staged
     const TapStep second = tap_step<S2>(1);
-    if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, 0, first.dy, first.dx);
-    if (!(a.dbg & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
+    if (!(SKY_DBG(a) & 2)) issue_halo(bimg, y0, x0, 0, first.dy, first.dx);
+    if (!(SKY_DBG(a) & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
     int nth = 0;
     for (;;) {
         int chunk = 0, q = 0;
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             const TapStep st = tap_step<S2>(q);
             if (st.newhalo && g > 0) {
                 __syncthreads();                       // every wave is done with the halo tile
-                if (!(a.dbg & 2)) issue_halo(bimg, y0, x0, chunk, st.dy, st.dx);
+                if (!(SKY_DBG(a) & 2)) issue_halo(bimg, y0, x0, chunk, st.dy, st.dx);
             }
             wait_vmcnt0();                              // this wave's DMA (slab g, the halo) has landed (and its older stores)
             __syncthreads();                           // ... and everybody else's; compute(g - 1) is over everywhere
@@ -377,8 +385,8 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             dbg_stamp(a, stamps, nth, 1 + 2 * g);
             // slabs 0 AND 1 of a tile are requested ahead of it (prologue / before the previous epilogue): behind that
             // epilogue's stores the first tap's DMA issue would stall for the length of the store drain (clock stamps)
-            if (g > 0 && g + 1 < G && !(a.dbg & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
-            if (!(a.dbg & 1)) compute_tap(st.tap, g & 1);
+            if (g > 0 && g + 1 < G && !(SKY_DBG(a) & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
+            if (!(SKY_DBG(a) & 1)) compute_tap(st.tap, g & 1);
             dbg_stamp(a, stamps, nth, 2 + 2 * g);
             q = nq;
             chunk = nchk;
@@ -391,13 +399,13 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             decode_tile(next, nb, ny0, nx0);
             __syncthreads();
             dbg_stamp(a, stamps, nth, 40);
-            if (!(a.dbg & 2)) issue_halo(nb, ny0, nx0, 0, first.dy, first.dx);
-            if (!(a.dbg & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
+            if (!(SKY_DBG(a) & 2)) issue_halo(nb, ny0, nx0, 0, first.dy, first.dx);
+            if (!(SKY_DBG(a) & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
         }
         dbg_stamp(a, stamps, nth, 41);
-        if (!(a.dbg & 8)) epilogue_act(bimg, y0, x0);
+        if (!(SKY_DBG(a) & 8)) epilogue_act(bimg, y0, x0);
         dbg_stamp(a, stamps, nth, 42);
-        if ((a.dbg & 256) && nth == 1) {
+        if ((SKY_DBG(a) & 256) && nth == 1) {
             wait_vmcnt0();
             dbg_stamp(a, stamps, nth, 43);
         }
@@ -405,7 +413,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
         if (next >= ntile) break;
         tile = next; bimg = nb; y0 = ny0; x0 = nx0;
     }
-    if ((a.dbg & 256) && a.raw && nth >= 2 && threadIdx.x == 0 && blockIdx.y == 0) {
+    if ((SKY_DBG(a) & 256) && a.raw && nth >= 2 && threadIdx.x == 0 && blockIdx.y == 0) {
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.raw) + (size_t)blockIdx.x * 64;
         for (int k = 0; k < 44; ++k) dst[k] = stamps[k];
     }
@@ -811,32 +819,38 @@ template <typename T, int NF, bool SQ, bool S2, int FC = 0>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     ConvArgs a = a0;
+    constexpr int NB = NF * 16;
+#ifdef SKY_EXPERIMENTS
     const char* dbg = getenv("SKY_CONV_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
-    constexpr int NB = NF * 16;
-    size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0) + ((a.dbg & 256) ? 512 : 0) + ((size_t)((a.dbg >> 16) & 0xff) << 10);
-    // SKY_HALO_NF8=solo (experiments): 128-channel tiles alone on a CU -- an LDS request above half of the CU's 160 KB excludes a second one
-    const char* nf8_env = getenv("SKY_HALO_NF8");
-    const bool solo = NF == 8 && nf8_env && nf8_env[0] == 's';
+#else
+    a.dbg = 0;
+#endif
+    size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
+#ifdef SKY_EXPERIMENTS
+    lds += ((a.dbg & 256) ? 512 : 0) + ((size_t)((a.dbg >> 16) & 0xff) << 10);
+#endif
+    // OPT_NF8_SOLO (A/B): 128-channel tiles alone on a CU -- an LDS request above half of the CU's 160 KB excludes a second one
+    const bool solo = NF == 8 && (a.opts & OPT_NF8_SOLO);
     if (solo && lds < 84 * 1024) lds = 84 * 1024;
     auto kern = conv_halo_kernel<T, NF, SQ, S2, FC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t attr[16] = {0};
+    {   // the attribute is set to the largest size this kernel can ever ask for (solo / padded variants included)
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds > 84 * 1024 ? lds : 84 * 1024, a.device, attr);
         if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    if (a.dbg & 64) {
-        int nb = -1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), HWV * 64, lds) != hipSuccess) nb = -1;
-        fprintf(stderr, "conv_halo<NF=%d>: %d workgroups per CU with %zu B of LDS\n", NF, nb, lds);
     }
     const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
     // two workgroups per CU in total: with several N tiles the tile range is split over fewer, longer-lived workgroups
     const int gy = a.Cout / NB;
     const int per_cu = solo ? 1 : 2;
-    const int slots = getenv("SKY_STREAM_OLDGRID") ? per_cu * n_cu : (per_cu * n_cu / gy > 0 ? per_cu * n_cu / gy : 1);
+    const int slots = (a.opts & OPT_OLDGRID) ? per_cu * n_cu : (per_cu * n_cu / gy > 0 ? per_cu * n_cu / gy : 1);
     int gx = ntile < slots ? ntile : slots;
+#ifdef SKY_EXPERIMENTS
+    if (a.dbg & 64) {
+        int nb = -1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), HWV * 64, lds) != hipSuccess) nb = -1;
+        fprintf(stderr, "conv_halo<NF=%d>: %d workgroups per CU with %zu B of LDS\n", NF, nb, lds);
+    }
     if ((a.dbg & 128) && gx > n_cu) gx = n_cu;
     static unsigned long long* stamps = nullptr;
     if (a.dbg & 256) {
@@ -844,7 +858,9 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
         if (hipMemsetAsync(stamps, 0, 1024 * 64 * 8, s) != hipSuccess) return hipErrorUnknown;
         a.raw = reinterpret_cast<float*>(stamps);
     }
+#endif
     kern<<<dim3(gx, a.Cout / NB), dim3(HWV * 64), lds, s>>>(a);
+#ifdef SKY_EXPERIMENTS
     if (a.dbg & 256) {   // experiment: mean timeline of every workgroup's second tile (shader clocks since its start)
         static int once = 0;
         if (once++ == 2 && hipStreamSynchronize(s) == hipSuccess) {
@@ -863,6 +879,7 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
             }
         }
     }
+#endif
     return hipGetLastError();
 }
 
@@ -872,11 +889,10 @@ static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
     constexpr int NB = NF * 16, NSLAB = (9 * CB + 255) / 256;
     const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + NB * 4 + (SRC == 1 ? 3 * 36 * 40 + 256 * sizeof(T) : 0);
     auto kern = conv_halo_small_kernel<T, CB, NF, SQ, SRC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t attr[16] = {0};
+    {
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;
     const int ntile = a.B * ((a.H + a.tile_h - 1) / a.tile_h) * ((a.W + a.tile_w - 1) / a.tile_w);
@@ -893,11 +909,10 @@ static hipError_t halo_small_s2_launch(const ConvArgs& a, hipStream_t s, int n_c
     constexpr int NB = NF * 16;
     const size_t lds = (size_t)3 * NB * 256 + 2 * 4 * SPL + NB * 4;
     auto kern = conv_halo_small_s2_kernel<T, NF, SQ>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t attr[16] = {0};
+    {
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;
     const int ntile = a.B * ((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w);
@@ -937,16 +952,14 @@ static bool halo_small_ok(int dtype, ConvArgs& a)
     const long cb = (long)a.Cin * esz;
     if (!((cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0))) return false;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz || (long)a.Cout * a.Kpad * esz >= (1L << 31)) return false;
-    const char* mode = getenv("SKY_CONV_HALO");
-    if (mode && mode[0] == '0') return false;
+    if (a.opts & OPT_HALO_OFF) return false;
     const double cover = pick_tile(a, SPX);
-    return (mode && mode[0] == 'f') || cover >= 0.75;
+    return (a.opts & OPT_HALO_FORCE) || cover >= 0.75;
 }
 
 bool conv_accepts_raw(int dtype, const ConvArgs& a0)
 {
-    static const bool off = getenv("SKY_NO_FUSED_IMPORT") != nullptr;       // A/B switch
-    if (off) return false;
+    if (a0.opts & OPT_NO_FUSED_IMPORT) return false;       // A/B switch
     ConvArgs a = a0;
     a.src_mode = 1;
     // the raw loader stages 16 x 16 tiles; dword loads want an even map width (raw width a multiple of 4)
@@ -957,13 +970,7 @@ bool conv_accepts_raw(int dtype, const ConvArgs& a0)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* variant, int* fused)
 {
     ConvArgs a = a0;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int esz = dtype == 0 ? 4 : 2;
     if (a.ks != 3 || (a.stride != 1 && a.stride != 2) || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
     if ((!a.src_mode && a.in_bytes == 0) || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
@@ -974,8 +981,7 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         if ((long)a.Kpad * esz < 9L * a.Cin * esz || (long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
         // measured slower than the streaming kernel on its one layer of skyeye_s (32 -> 64 @640 -> 320: 0.385 vs 0.336 ms, the
         // layer is HBM-bound and four DMA phases per tile cost more than they save): only used when forced (tests)
-        const char* md = getenv("SKY_CONV_HALO");
-        if (!(md && md[0] == 'f')) return hipErrorNotSupported;
+        if (!(a.opts & OPT_HALO_FORCE)) return hipErrorNotSupported;
         pick_tile(a, SPX);
         const bool sq2 = a.tile_w == 16 && a.tile_h == 16;
         hipError_t e2;
@@ -992,20 +998,18 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     if (!small && (a.src_mode || cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
-    const char* mode = getenv("SKY_CONV_HALO");   // "0": never, "force": whenever the shape is covered
-    if (mode && mode[0] == '0') return hipErrorNotSupported;
+    if (a.opts & OPT_HALO_OFF) return hipErrorNotSupported;
     {   // bisection switch: SKY_HALO_SKIP bit 0 = stride-1 kernel, 1 = stride-2 kernel, 2 = narrow kernels, 3 = 128-channel tiles, 4 = 64-channel tiles
-        static const int skip = getenv("SKY_HALO_SKIP") ? atoi(getenv("SKY_HALO_SKIP")) : 0;
+        const int skip = (int)(a.opts >> OPT_SKIP_SHIFT) & 31;
         if (small ? (skip & 4) : (a.stride == 2 ? (skip & 2) : (skip & 1))) return hipErrorNotSupported;
         if (!small && ((a.Cout % 128 == 0) ? (skip & 8) : (skip & 16))) return hipErrorNotSupported;
     }
     if (!small && a.stride == 2) {      // A/B switch: SKY_HALO_S2=0 sends stride-2 layers to the streaming kernel
-        const char* s2 = getenv("SKY_HALO_S2");
-        if (s2 && s2[0] == '0') return hipErrorNotSupported;
+        if (a.opts & OPT_S2_OFF) return hipErrorNotSupported;
     }
     const double cover = pick_tile(a, small ? SPX : HPIX);
     // partially filled tiles waste matrix work: keep the streaming kernel when less than 3/4 of the tile grid is image
-    if (!(mode && mode[0] == 'f') && cover < 0.75) return hipErrorNotSupported;
+    if (!(a.opts & OPT_HALO_FORCE) && cover < 0.75) return hipErrorNotSupported;
     if (small) {
         const int nb = a.Cout == 32 ? 32 : 64;
         const hipError_t e = dtype == 0 ? halo_small_dispatch<float>((int)cb, nb, a, s, n_cu) : halo_small_dispatch<__bf16>((int)cb, nb, a, s, n_cu);
@@ -1014,8 +1018,7 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     }
     // 128-channel tiles where Cout allows (two workgroups per CU).  A/B switches: SKY_HALO_NF8=off -> 64-channel tiles everywhere,
     // SKY_HALO_NF8=solo -> 128-channel tiles alone on a CU (3x3 128->128 @80x80: 74.5 us default, 82 us off, 96 us solo)
-    const char* nf8_sel = getenv("SKY_HALO_NF8");
-    const int nb = (a.Cout % 128 == 0 && !(nf8_sel && nf8_sel[0] == 'o')) ? 128 : 64;
+    const int nb = (a.Cout % 128 == 0 && !(a.opts & OPT_NF8_OFF)) ? 128 : 64;
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
     if (a.stride == 2) {

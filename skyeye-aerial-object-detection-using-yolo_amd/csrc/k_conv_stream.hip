@@ -413,8 +413,7 @@ static StreamPlan stream_plan(int dtype, const ConvArgs& a)
     const long Kb = (long)a.ks * a.ks * Cb;
     const long nslab = (Kb + SLAB - 1) / SLAB;
     if ((long)a.Kpad * esz < nslab * SLAB) return p;                       // packed rows must cover whole slabs
-    static const bool no_ring = getenv("SKY_NO_RING") != nullptr;
-    const bool ring_ok = !no_ring && a.Cout % 128 == 0;
+    const bool ring_ok = !(a.opts & OPT_NO_RING) && a.Cout % 128 == 0;
     int fallback = 0;
     for (int nf : {8, 4, 2}) {                                             // resident weights
         const int nb = nf * 16;
@@ -446,12 +445,11 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     const size_t Kb = (size_t)KS * KS * a.Cin * sizeof(T);
     const size_t nslab = (Kb + SLAB - 1) / SLAB;
     const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
-    static size_t attr_lds = 0;
+    static size_t attr[16] = {0};
     auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT, ONE, FC>;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
         if (e != hipSuccess) return e;
-        attr_lds = lds;
     }
     const int ntiles = (a.M + TPX - 1) / TPX;
     int gx = (ntiles + SW - 1) / SW;
@@ -459,7 +457,7 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     // range is split over n_cu / gy persistent workgroups each, instead of gy rounds of short-lived ones that would each
     // pay the prologue (bias, first weight slab, first pixel slab) again
     const int gy = a.Cout / NB;
-    const int cap = getenv("SKY_STREAM_OLDGRID") ? n_cu : (n_cu / gy > 0 ? n_cu / gy : 1);
+    const int cap = (a.opts & OPT_OLDGRID) ? n_cu : (n_cu / gy > 0 ? n_cu / gy : 1);
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(kern, dim3(gx, a.Cout / NB), dim3(SW * 64), lds, s, a);
     return hipGetLastError();
@@ -541,13 +539,7 @@ static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipS
 // returns hipErrorNotSupported when the shape is not covered (caller falls back to the implicit-GEMM kernel)
 hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     if (a.src_mode) return hipErrorNotSupported;
     const StreamPlan p = stream_plan(dtype, a);
     if (p.nf == 0) return hipErrorNotSupported;

@@ -47,6 +47,10 @@ __device__ __forceinline__ void row_entries(const NmsArgs& a, const float* __res
     const int nc = a.nc;
     const float obj = p[4];
     if (!(obj > a.conf)) return;                                   // metrics.py:389,402
+    if (a.mode == 2) {                                             // rows that are already boxes: x1, y1, x2, y2, conf, cls
+        if (class_ok(a, p[5])) f(obj, p[5], 0.0f);                 // (second stage of the tiled path: survivors of the per-tile NMS)
+        return;
+    }
     if (a.mode == 0) {
         if (nc > 1) {
             if (a.multi_label) {                                   // metrics.py:412-413
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(64) nms_greedy_kernel(const NmsArgs a)
             const float* r = a.cand + ((long)b * a.cap + ci) * 4;
             score = r[0]; c5 = r[1]; c6 = r[2];
             const float* p = a.det + ((long)b * a.N + __float_as_int(r[3])) * no;
-            if (a.mode == 0) { b0 = p[0]; b1 = p[1]; b2 = p[2]; b3 = p[3]; }
+            if (a.mode == 0 || a.mode == 2) { b0 = p[0]; b1 = p[1]; b2 = p[2]; b3 = p[3]; }
             else {
                 const float hw = p[2] / 2.0f, hh = p[3] / 2.0f;
                 b0 = p[0] - hw; b1 = p[1] - hh; b2 = p[0] + hw; b3 = p[1] + hh;
@@ -288,6 +292,9 @@ __global__ void __launch_bounds__(64) nms_greedy_kernel(const NmsArgs a)
         __syncthreads();   // single wave: orders the LDS writes of kb before the next block's reads
     }
     if (lane == 0) a.counts[b] = kept;
+    // rows past the kept ones are defined (zeros): callers hand over uninitialised buffers and the fixed-capacity block
+    // that travels through the RCCL all-gather is the same bytes on every run
+    for (int i = kept * 7 + lane; i < a.max_det * 7; i += 64) out[i] = 0.0f;
 }
 
 static long next_pow2(long v)
@@ -318,11 +325,10 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
     hipLaunchKernelGGL(nms_emit_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
     hipLaunchKernelGGL(nms_pad_kernel, dim3((unsigned)((a.cap + 255) / 256), a.B), dim3(256), 0, s, a);
     const unsigned chunks = (unsigned)((a.cap + CHUNK - 1) / CHUNK);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHUNK * 8);
+    static size_t attr[16] = {0};
+    {
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(nms_sort_lds_kernel), CHUNK * 8, a.device, attr);
         if (e != hipSuccess) return e;
-        attr = true;
     }
     hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 1, 0L);
     for (long k = 2L * CHUNK; k <= a.cap; k <<= 1) {

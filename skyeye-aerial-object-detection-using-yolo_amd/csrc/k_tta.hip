@@ -125,6 +125,29 @@ hipError_t launch_map_detections(const float* src, int B, int N, int no, int row
     return hipGetLastError();
 }
 
+// Survivors of a per-tile NMS (corner rows x1, y1, x2, y2, ...) moved into the frame of the whole image, in place: rows
+// [0, counts[t]) of tile t get x += origin_x, y += origin_y; the zero rows past the count stay zero.
+__global__ void offset_boxes_kernel(float* __restrict__ rows, const int* __restrict__ counts, int T, int R, int cols, const int* __restrict__ origins)
+{
+    const long total = (long)T * R * 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 3);
+        const long q = i >> 2;
+        const int r = (int)(q % R), t = (int)(q / R);
+        if (r >= counts[t]) continue;
+        float* p = rows + ((long)t * R + r) * cols + c;
+        *p = *p + (float)origins[2 * t + ((c & 1) ? 0 : 1)];
+    }
+}
+
+hipError_t launch_offset_boxes(float* rows, const int* counts, int T, int R, int cols, const int* origins, hipStream_t s)
+{
+    const long total = (long)T * R * 4;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(offset_boxes_kernel, dim3(tta_grid((total + 255) / 256)), dim3(256), 0, s, rows, counts, T, R, cols, origins);
+    return hipGetLastError();
+}
+
 // One thread = 4 consecutive output bytes of one row of one channel of one tile.
 __global__ void tile_gather_kernel(const unsigned char* __restrict__ src, int H0, int W0, int src_chw, const int* __restrict__ origins, int n,
                                    unsigned char* __restrict__ dst, int th, int tw, int pad, int rev)

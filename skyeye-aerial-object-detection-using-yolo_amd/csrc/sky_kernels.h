@@ -12,6 +12,37 @@ namespace sky {
 
 enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 
+// Developer A/B switches.  They are read from the environment ONCE, by sky_plan (engine.cpp: read_plan_opts), stored with the
+// plan, reported by sky_op_info and handed to the launchers as a bit set: no launcher calls getenv, so an environment variable
+// that appears after planning cannot re-route a planned graph.  None is needed in production; the parity tests use them to
+// force a kernel path (tests/test_gpu_conv_halo.py, test_gpu_determinism.py).
+enum PlanOpt : unsigned {
+    OPT_HALO_OFF = 1u << 0,          // SKY_CONV_HALO=0      halo-tile kernels never
+    OPT_HALO_FORCE = 1u << 1,        // SKY_CONV_HALO=force  halo-tile kernels whenever the shape is covered
+    OPT_NF8_OFF = 1u << 2,           // SKY_HALO_NF8=off     64-channel tiles everywhere
+    OPT_NF8_SOLO = 1u << 3,          // SKY_HALO_NF8=solo    128-channel tiles alone on a CU
+    OPT_S2_OFF = 1u << 4,            // SKY_HALO_S2=0        stride-2 layers on the streaming kernel
+    OPT_NO_STREAM = 1u << 5,         // SKY_NO_STREAM        implicit-GEMM tile kernel for everything
+    OPT_NO_RING = 1u << 6,           // SKY_NO_RING
+    OPT_OLDGRID = 1u << 7,           // SKY_STREAM_OLDGRID
+    OPT_NO_FUSED_IMPORT = 1u << 8,   // SKY_NO_FUSED_IMPORT  stem reads an imported tensor instead of the raw frames
+    OPT_FUSE = 1u << 9,              // SKY_FUSE=1           1x1 convolutions in the producer's epilogue (measured neutral)
+    OPT_NO_SPP_PYRAMID = 1u << 10,   // SKY_NO_SPP_PYRAMID
+    OPT_ATTN_VALU = 1u << 11,        // SKY_ATTN_VALU        exact attention core for bf16 too
+    OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: `state` is a function-local static of each launcher,
+// one slot per device ordinal, holding the largest LDS size already granted there.
+inline hipError_t ensure_lds_attr(const void* kern, size_t lds, int device, size_t (&state)[16])
+{
+    const int d = device >= 0 && device < 16 ? device : 0;
+    if (lds <= state[d] && state[d] != 0) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) state[d] = lds;
+    return e;
+}
+
 // One fused convolution launch: out = act(conv(in, w) + bias) (+ res), optionally written 2x-upsampled
 // (nearest) or decoded as a detection level.
 struct ConvArgs {
@@ -33,7 +64,9 @@ struct ConvArgs {
     int cpt_shift;       // log2(16-byte chunks per tap) or -1 (streaming kernel)
     int tile_w, tile_h;         // halo-tile kernels: output tile shape (tile_w * tile_h <= 256)
     unsigned magic_w, magic_h;  // halo-tile kernels: 2^16 / tile_w + 1, 2^16 / (tile_w + 2) + 1 (exact division of small indices)
-    int dbg;             // kernel experiments (SKY_CONV_DBG), 0 in production
+    int dbg;             // kernel experiments (SKY_CONV_DBG): only read by builds with -DSKY_EXPERIMENTS, ignored otherwise
+    unsigned opts;       // PlanOpt bits of the plan
+    int device, n_cu;    // device ordinal of the plan and its CU count (per-device launch geometry / LDS attributes)
     int src_mode;        // 0: `in` is an NHWC tensor of T.  1 / 2: `in` is the caller's raw [B, 3, 2H, 2W] uint8 / float32 NCHW
                          // frame batch and FocusBlock's space-to-depth + /255 + conversion are fused into the convolution's
                          // loader (narrow-input halo kernel only; conv_accepts_raw() tells whether a launch would take it)
@@ -132,7 +165,7 @@ hipError_t launch_layernorm(int dtype, const void* x, int ldx, void* y, int ldy,
 // qkv [G, N, 3C] -> out [G, N, C]; bias [heads, N, N] and mask [nW, N, N] optional (fp32).  ws > 0: the G groups are
 // the ws x ws windows of a [B, mh, mw] NHWC map addressed in place (N = ws * ws)
 hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale,
-                            const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s);
+                            const float* bias, const float* mask, int nW, int ws, int mh, int mw, hipStream_t s, unsigned opts = 0);
 // CrossLayerAttention core: q [B,H,W,C], kv [B,h,w,2C] (v at channel offset v_off), scores scratch [B,H,W,heads] fp32
 hipError_t launch_cla(int dtype, const void* q, int ldq, const void* kv, int ldkv, int v_off, float* scores, void* out, int ldo, int B, int H,
                       int W, int h, int w, int C, int heads, float scale, float r2, hipStream_t s);
@@ -154,6 +187,7 @@ struct NmsArgs {
     unsigned long long* keys;  // [B, cap]
     float* cand;        // [B, cap, 4]  (score, conf, class, src row as int bits)
     long cap;           // power of two >= N * (multi_label ? nc : 1)
+    int device;         // device ordinal of the handle (per-device LDS attribute)
 };
 size_t nms_workspace_bytes(int B, int N, int nc, int multi_label, long* cap_out);
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
@@ -165,6 +199,7 @@ hipError_t launch_scale_img(const void* src, int src_u8, int planes, int H, int 
                             hipStream_t s);
 hipError_t launch_map_detections(const float* src, int B, int N, int no, int row0, int rows, float scale, int flip, float img_h, float img_w,
                                  const int* origins, int tpi, float* dst, long dst_rows, long dst_row0, hipStream_t s);
+hipError_t launch_offset_boxes(float* rows, const int* counts, int T, int R, int cols, const int* origins, hipStream_t s);
 hipError_t launch_tile_gather(const unsigned char* src, int H0, int W0, int src_chw, const int* origins, int n, unsigned char* dst, int th, int tw,
                               int pad, int rev, hipStream_t s);
 

@@ -56,7 +56,7 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
+           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_offset_boxes", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
 _lib = None
 
@@ -113,6 +113,7 @@ def lib():
     fp = ctypes.c_float
     L.sky_scale_img.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, ip, ip, fp, vp]
     L.sky_map_detections.argtypes = [vp, vp, ip, ip, ip, ip, ip, fp, ip, fp, fp, vp, ip, vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.sky_offset_boxes.argtypes = [vp, vp, vp, ip, ip, ip, vp, vp]
     L.sky_tile_gather.argtypes = [vp, vp, ip, ip, ip, vp, ip, vp, ip, ip, ip, ip, vp]
     _lib = L
     return L
@@ -254,6 +255,11 @@ class Handle:
         f, a, w, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
         check(self.L.sky_plan_stats(self.h, ctypes.byref(f), ctypes.byref(a), ctypes.byref(w), ctypes.byref(n)), self.h)
         return dict(flops=f.value, activation_bytes=a.value, weight_bytes=w.value, launches=n.value)
+
+
+def null_buffer():
+    """An optional output the caller does not want (sky_forward: raw detection levels may be NULL)."""
+    return SkyBuffer()
 
 
 def buffer_from_tensor(t, layout=SKY_NCHW):

@@ -6,6 +6,7 @@ engine (``sky_forward``).  There is deliberately no PyTorch implementation of th
 without the native library or without a HIP device ``forward`` raises.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -14,9 +15,38 @@ import torch.nn as nn
 from ... import _native as N
 
 
+# Weight staleness.  An engine packs (BN-folds, converts) the weights once; it must notice every later change, also the ones
+# that never pass through the NativeModule that owns the engine: ``model.backbone.load_state_dict(sd)`` on a plain nn.Module
+# child, ``p.data.copy_()``, an optimizer step.  Two cheap signals cover them:
+#   * _EPOCH, a process-wide counter bumped whenever a tensor attribute is (re)bound or a module is moved / cast
+#     (``_apply``): the cached list of a module's tensors is rebuilt when it moved;
+#   * the sum of ``tensor._version`` over that list (in-place writes bump it), taken on every forward (~75 us for skyeye_s).
+_EPOCH = [0]
+
+# developer switches read by sky_plan (csrc/sky_kernels.h PlanOpt): part of the engine cache key, so that a test which
+# toggles one between two calls of the same module gets a plan made under the new value
+_PLAN_SWITCHES = ("SKY_CONV_HALO", "SKY_HALO_NF8", "SKY_HALO_S2", "SKY_NO_STREAM", "SKY_NO_RING", "SKY_STREAM_OLDGRID",
+                  "SKY_NO_FUSED_IMPORT", "SKY_FUSE", "SKY_NO_FUSE", "SKY_NO_SPP_PYRAMID", "SKY_ATTN_VALU", "SKY_HALO_SKIP",
+                  "SKY_NO_FUSE_CV1", "SKY_FP8_PLAIN")
+
+
+def _bump_epoch():
+    _EPOCH[0] += 1
+
+
 # ----------------------------------------------------------------------------- parameter holders
 class _Holder(nn.Module):
     """A module that only owns tensors (same names / shapes as the torch.nn layer it stands for)."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor):
+            _bump_epoch()
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        _bump_epoch()
+        return r
 
     def forward(self, *a, **k):  # pragma: no cover - guard
         raise RuntimeError(f"{type(self).__name__} only holds parameters; computation runs inside libskyeye_hip.so "
@@ -91,9 +121,15 @@ class NativeModule(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.__dict__["_engines"] = {}      # (precision, device, shapes) -> (Handle, weights_version)
+        self.__dict__["_engines"] = {}      # (precision, device, shapes, switches) -> (Handle, weights fingerprint)
         self.__dict__["_weights_version"] = 0
         self.__dict__["_precision"] = None   # None: follow parameter dtype (fp32 -> exact, half/bf16 -> bf16)
+        self.__dict__["_out_cache"] = None   # reuse_output_buffers(True): {engine key: output tensors}
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor):
+            _bump_epoch()
+        super().__setattr__(name, value)
 
     # -- configuration handed to sky_create; subclasses override
     def _sky_config(self):
@@ -111,10 +147,33 @@ class NativeModule(nn.Module):
         return r
 
     def refresh_weights(self):
-        """Call after editing parameters in place: engines re-pack weights on the next forward."""
+        """Force engines to re-pack weights on the next forward.  Not needed after in-place edits of the parameters themselves
+        (``p.mul_()``, ``p.copy_()`` under no_grad, an optimizer step) or ``load_state_dict`` on any sub-module:
+        ``_weights_fingerprint`` sees those.  Needed after writes through ``p.data`` (a detached alias with its own version
+        counter: nothing cheap can see them)."""
+        _bump_epoch()
         for m in self.modules():
             if isinstance(m, NativeModule):
                 m.__dict__["_weights_version"] = m.__dict__.get("_weights_version", 0) + 1
+
+    def _weights_fingerprint(self):
+        """(explicit refresh counter, identity of the tensors, sum of their in-place versions)."""
+        st = self.__dict__
+        if st.get("_fp_epoch") != _EPOCH[0]:
+            ts = [t for t in self.state_dict(keep_vars=True).values() if t.dtype != torch.long]
+            st["_fp_tensors"] = ts
+            st["_fp_ident"] = hash(tuple((id(t), t.data_ptr()) for t in ts))
+            st["_fp_epoch"] = _EPOCH[0]
+        v = 0
+        for t in st["_fp_tensors"]:
+            v += t._version
+        return (st["_weights_version"], st["_fp_ident"], v)
+
+    def reuse_output_buffers(self, on=True):
+        """Steady-state serving: ``forward`` returns the SAME output tensors on every call of a given geometry (the caller must
+        be done with the previous results) instead of allocating ~12 MB per 1280x1280 frame.  Off by default."""
+        self.__dict__["_out_cache"] = {} if on else None
+        return self
 
     def set_precision(self, precision):
         """'fp32' (exact MFMA f32 path) or 'bf16' (production).  None = follow the parameter dtype like the
@@ -164,12 +223,16 @@ class NativeModule(nn.Module):
     def _engine(self, inputs, extra_cfg=None):
         prec = self._resolved_precision()
         dev = inputs[0].device
-        key = (prec, dev.index or 0, tuple(tuple(t.shape) for t in inputs), tuple(sorted((extra_cfg or {}).items())))
+        key = (prec, dev.index or 0, tuple(tuple(t.shape) for t in inputs), tuple(sorted((extra_cfg or {}).items())),
+               tuple(os.environ.get(k) for k in _PLAN_SWITCHES))
+        fp = self._weights_fingerprint()
         ent = self._engines.get(key)
-        if ent is not None and ent[1] == self._weights_version:
+        if ent is not None and ent[1] == fp:
             return ent[0]
         if ent is not None:
             ent[0].close()
+            if self._out_cache is not None:
+                self._out_cache.pop(id(ent[0]), None)
         if len(self._engines) >= 6:                       # keep a few geometries resident (test-time augmentation plans three)
             old, _ = self._engines.pop(next(iter(self._engines)))     # the oldest plan goes first
             old.close()
@@ -181,7 +244,7 @@ class NativeModule(nn.Module):
         if w:
             h.load_weights(w)
         h.plan([N.buffer_from_tensor(t) for t in inputs])
-        self._engines[key] = (h, self._weights_version)
+        self._engines[key] = (h, fp)
         return h
 
     def export_engine(self, path, *example_inputs):
@@ -212,13 +275,22 @@ class NativeModule(nn.Module):
             t = t.float()
         return t.contiguous()
 
-    def _run(self, inputs, extra_cfg=None):
+    def _run(self, inputs, extra_cfg=None, skip=()):
+        """``skip``: indices of optional outputs the caller does not want (the raw detection levels): the engine gets a NULL
+        buffer for them and does not write them; the returned list holds None there."""
         inputs = [self._prepare_input(t) for t in inputs]
         h = self._engine(inputs, extra_cfg)
-        outs = [torch.empty(s, dtype=torch.float32, device=inputs[0].device) for s in h.output_shapes()]
+        cache = self._out_cache
+        outs = cache.get(id(h)) if cache is not None else None
+        if outs is None or any((o is None) != (i in skip) for i, o in enumerate(outs)):
+            outs = [None if i in skip else torch.empty(s, dtype=torch.float32, device=inputs[0].device)
+                    for i, s in enumerate(h.output_shapes())]
+            if cache is not None:
+                cache[id(h)] = outs
         stream = torch.cuda.current_stream(inputs[0].device).cuda_stream
-        h.forward([N.buffer_from_tensor(t) for t in inputs], [N.buffer_from_tensor(t) for t in outs], stream)
-        return outs
+        h.forward([N.buffer_from_tensor(t) for t in inputs],
+                  [N.null_buffer() if t is None else N.buffer_from_tensor(t) for t in outs], stream)
+        return list(outs)
 
     def forward(self, x):
         return self._run([x])[0]

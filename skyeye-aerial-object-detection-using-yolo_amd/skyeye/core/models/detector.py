@@ -161,14 +161,18 @@ class SkyEyeDetector(NativeModule):
                     width_multiple=float(self.cfg.get("width_multiple", 1.0)), nc=self.cfg["nc"], in_channels=3,
                     anchors=self.detection_head.anchors, head_attention=bool(self.cfg.get("head_attention", False)))
 
-    def forward(self, x, augment=False, visualize=False):
+    def forward(self, x, augment=False, visualize=False, return_raw=True):
         """eval: (detections [B, N, nc+5], [raw_P3, raw_P4, raw_P5]); train: raw list (detector.py:300-324).
+        ``return_raw=False`` (eval only; an extension for callers that go straight to NMS, as validate.py:245-255 does): the
+        engine skips the stores of the three raw levels (6 MB fp32 per 1280x1280 frame) and the second element is [].
         ``augment`` / ``visualize`` are accepted because the reference's callers pass them (validate.py:245, detect.py:140);
         ``augment=True`` (eval only) runs the 1 / 0.83-flipped / 0.67 schedule of ``skyeye.utils.tta.forward_augment`` and returns
         (detections [B, sum N_i, nc+5] in the frame of ``x``, None)."""
         if augment and not self.training:
             from ...utils.tta import forward_augment
             return forward_augment(lambda xi: self._run([xi])[0], x, gs=int(self.stride.max())), None
+        if not self.training and not return_raw:
+            return self._run([x], skip=(1, 2, 3))[0], []
         outs = self._run([x])
         if not self.training:
             return outs[0], outs[1:]

@@ -20,17 +20,18 @@ def shard_bounds(n_items, rank, world):
 
 
 def pack_detections(rows, counts):
-    """[B, max_det, 7] float32 + [B] int32 -> one [B, max_det*7 + 1] float32 buffer (count bit-cast into the last slot)."""
+    """[B, max_det, 7] float32 + [B] int32 -> one [B, max_det*7 + 1] float32 buffer; the count travels as float(count)
+    (exact up to 2^24; a bit-cast int32 would be a denormal that a flush-to-zero copy on the way may erase)."""
     B = rows.shape[0]
     packed = torch.empty((B, rows.shape[1] * rows.shape[2] + 1), dtype=torch.float32, device=rows.device)
     packed[:, :-1] = rows.reshape(B, -1)
-    packed[:, -1] = counts.to(torch.int32).view(torch.float32)
+    packed[:, -1] = counts.to(torch.float32)
     return packed
 
 
 def unpack_detections(packed, max_det, cols=7):
     rows = packed[:, :-1].reshape(packed.shape[0], max_det, cols)
-    counts = packed[:, -1].contiguous().view(torch.int32)
+    counts = packed[:, -1].to(torch.int32)
     return rows, counts
 
 

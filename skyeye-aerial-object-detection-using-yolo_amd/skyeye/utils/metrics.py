@@ -14,11 +14,12 @@ from .. import _native as N
 _UTIL = {}
 
 
-def _handle(device_index):
-    h = _UTIL.get(device_index)
+def _handle(device_index, stream=0):
+    """One utility handle (it owns the NMS workspace) per (device, stream): two streams never share a workspace."""
+    h = _UTIL.get((device_index, stream))
     if h is None:
         h = N.Handle(N.make_config("UTILITY", device=device_index))
-        _UTIL[device_index] = h
+        _UTIL[(device_index, stream)] = h
     return h
 
 
@@ -34,15 +35,16 @@ def nms_raw(prediction, conf_threshold=0.25, iou_threshold=0.45, classes=None, a
     p.conf_threshold, p.iou_threshold = float(conf_threshold), float(iou_threshold)
     p.agnostic, p.multi_label = int(bool(agnostic)), int(bool(multi_label))
     p.max_detections, p.max_nms, p.max_wh = int(max_detections), int(max_nms), float(max_wh)
-    p.mode = 0 if mode == "literal" else 1
+    p.mode = {"literal": 0, "corrected": 1, "rows": 2}[mode]
     cls = [] if classes is None else [int(c) for c in classes]
     p.n_classes = len(cls)
     for i, c in enumerate(cls):
         p.classes[i] = c
-    out = torch.zeros((B, max_detections, 7), dtype=torch.float32, device=pred.device)
-    counts = torch.zeros((B,), dtype=torch.int32, device=pred.device)
-    h = _handle(pred.device.index or 0)
+    # the kernel defines every element (rows past the count are zeroed, k_nms.hip: nms_greedy_kernel): no fill launches here
+    out = torch.empty((B, max_detections, 7), dtype=torch.float32, device=pred.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
     stream = torch.cuda.current_stream(pred.device).cuda_stream
+    h = _handle(pred.device.index or 0, stream)
     N.check(h.L.sky_nms(h.h, pred.data_ptr(), B, Nrows, no - 5, ctypes.byref(p), out.data_ptr(), counts.data_ptr(),
                         ctypes.c_void_p(stream)), h.h)
     return out, counts

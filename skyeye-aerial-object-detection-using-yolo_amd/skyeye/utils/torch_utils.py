@@ -52,3 +52,24 @@ def scale_img(img, ratio=1.0, same_shape=False, gs=32, flip=None):
     N.check(h.L.sky_scale_img(h.h, src.data_ptr(), N.SKY_IO_U8 if src.dtype == torch.uint8 else N.SKY_IO_F32, B, C, H, W, out.data_ptr(),
                               s[0], s[1], p[0], p[1], flip, 0.447, ctypes.c_void_p(stream)), h.h)
     return out
+
+
+def capture_graph(fn, warmup=2):
+    """Capture ``fn()`` -- a static-shape chain of engine calls such as forward + ``nms_raw``, no host synchronisation inside --
+    into ONE hipGraph: ``graph, outputs = capture_graph(step); graph.replay()`` re-runs all its launches (77 for skyeye_s plus
+    NMS) with a single host call and refreshes ``outputs`` in place.  The warm-up runs on the capture stream first, so that every
+    one-time allocation (plans, NMS workspace, LDS attributes) happens before the capture starts.  Inputs captured by ``fn``
+    must keep their storage; to feed new frames copy them into the captured input tensor."""
+    if not torch.cuda.is_available():
+        raise N.SkyEyeNativeError("capture_graph needs the HIP device (no CPU path)")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(1, warmup)):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        outputs = fn()
+    return graph, outputs

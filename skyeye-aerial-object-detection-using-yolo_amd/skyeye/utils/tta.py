@@ -127,3 +127,83 @@ def detect_tiled(model, frame, tile=1280, overlap=0.2, batch=None, chw=False, re
     if return_raw:
         return merged, org
     return non_max_suppression(merged, conf_thres, iou_thres, classes, agnostic, max_det=max_det, mode=nms_mode)[0]
+
+
+# ----------------------------------------------------------------------------- tiling across ranks ("Tiled (C5)")
+# The tiles of ONE frame may sit on different GPUs.  The path is two-stage whatever the number of ranks, so that its result
+# does not depend on it ("1-GPU tiled == 8-GPU tiled, exactly"):
+#   1. every rank: its contiguous shard of the tiles (skyeye.distributed.shard_bounds) -> forward -> per-tile NMS (<= tile_max_det
+#      survivors per tile, corner rows x1, y1, x2, y2, conf, cls) -> sky_offset_boxes moves them into frame coordinates;
+#   2. ONE all-gather of the fixed-capacity survivor blocks (RCCL over xGMI; every rank contributes ceil(n_tiles / world) blocks,
+#      the missing ones empty), which keeps the tiles in row-major order;
+#   3. the frame's owner rank: cross-tile NMS over the gathered rows (sky_nms mode 2, "rows").
+def tile_shard(n_tiles, rank, world):
+    """-> (lo, hi, per): this rank's contiguous tiles [lo, hi) and the common block count per rank of the gather."""
+    from ..distributed import shard_bounds
+    lo, hi = shard_bounds(n_tiles, rank, world)
+    return lo, hi, -(-n_tiles // world)
+
+
+@torch.no_grad()
+def tile_survivors(model, frame, origins_np, tile_hw, per, batch=None, chw=False, reverse_channels=False, conf_thres=0.25, iou_thres=0.45,
+                   classes=None, agnostic=False, tile_max_det=300):
+    """Stage 1 for the tiles at ``origins_np`` (int32 [t, 2], t <= per): -> (rows [per, tile_max_det, 7], counts [per]) on the
+    device, boxes in FRAME pixels; blocks t .. per-1 are empty (zero rows, count 0)."""
+    from .metrics import nms_raw
+    th, tw = tile_hw
+    dev = frame.device
+    rows = torch.zeros((per, tile_max_det, 7), dtype=torch.float32, device=dev)
+    counts = torch.zeros((per,), dtype=torch.int32, device=dev)
+    t = len(origins_np)
+    if t == 0:
+        return rows, counts
+    batch = t if batch is None else max(1, min(int(batch), t))
+    t_pad = -(-t // batch) * batch
+    org_pad = np.concatenate([origins_np, np.repeat(origins_np[-1:], t_pad - t, 0)], 0).astype(np.int32)
+    origins = torch.from_numpy(org_pad).to(dev)
+    tiles = tile_gather(frame, origins, th, tw, chw=chw, reverse_channels=reverse_channels)
+    h = _handle(dev.index or 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for i in range(0, t_pad, batch):
+        det = model(tiles[i:i + batch])
+        det = det[0] if isinstance(det, (tuple, list)) else det
+        r, c = nms_raw(det, conf_thres, iou_thres, classes, agnostic, max_detections=tile_max_det, mode="corrected")
+        valid = min(batch, t - i)
+        r, c = r[:valid].contiguous(), c[:valid].contiguous()
+        N.check(h.L.sky_offset_boxes(h.h, r.data_ptr(), c.data_ptr(), valid, tile_max_det, 7, origins[i:i + valid].data_ptr(),
+                                     ctypes.c_void_p(stream)), h.h)
+        rows[i:i + valid] = r
+        counts[i:i + valid] = c
+    return rows, counts
+
+
+def merge_tile_survivors(rows, counts, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000):
+    """Stage 3: cross-tile NMS over gathered survivor blocks rows [T, R, 7] -> [k, 6] (x1, y1, x2, y2, conf, cls).  Empty
+    blocks and the zero rows past each count have conf 0 and never pass the threshold."""
+    from .metrics import non_max_suppression
+    flat = rows.reshape(1, -1, rows.shape[-1]).contiguous()
+    return non_max_suppression(flat, conf_thres, iou_thres, classes, agnostic, max_det=max_det, mode="rows")[0]
+
+
+@torch.no_grad()
+def detect_tiled_sharded(model, frame, tile=1280, overlap=0.2, batch=None, chw=False, reverse_channels=False, conf_thres=0.25,
+                         iou_thres=0.45, classes=None, agnostic=False, max_det=1000, tile_max_det=300, group=None, owner=None):
+    """Tiled detection of one frame with its tiles sharded over the ranks of ``group`` (every rank holds ``frame``; None or an
+    uninitialised process group = one rank).  ``owner``: the rank that runs the cross-tile NMS and returns the [k, 6] rows (the
+    others return None); None = every rank computes the (identical) result.  The result is the same for any world size."""
+    import torch.distributed as dist
+    from ..distributed import all_gather_detections
+    live = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    th, tw = (tile, tile) if isinstance(tile, int) else tile
+    H0, W0 = (frame.shape[1], frame.shape[2]) if chw else (frame.shape[0], frame.shape[1])
+    org = tile_origins(H0, W0, th, tw, overlap)
+    lo, hi, per = tile_shard(len(org), rank, world)
+    rows, counts = tile_survivors(model, frame, org[lo:hi], (th, tw), per, batch, chw, reverse_channels, conf_thres, iou_thres, classes,
+                                  agnostic, tile_max_det)
+    if world > 1:
+        rows, counts = all_gather_detections(rows, counts, group)
+    if owner is not None and rank != owner:
+        return None
+    return merge_tile_survivors(rows, counts, conf_thres, iou_thres, classes, agnostic, max_det)

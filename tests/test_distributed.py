@@ -68,3 +68,72 @@ def test_all_gather_of_boxes_world2_gloo():
         # every rank holds the same rank-ordered result, bit for bit == the single-process result
         assert np.array_equal(rows.view(np.uint32), expect_rows.view(np.uint32))
         assert np.array_equal(counts, expect_counts)
+
+
+# ---- tiled inference: the tiles of one frame on different ranks (SURVEY 8e "Tiled (C5)") -------------------------------------
+def _fake_survivors(n_tiles, R):
+    """deterministic per-tile survivor blocks (what stage 1 of skyeye.utils.tta.detect_tiled_sharded produces)"""
+    g = torch.Generator().manual_seed(77)
+    counts = torch.randint(0, R + 1, (n_tiles,), generator=g, dtype=torch.int32)
+    rows = torch.rand((n_tiles, R, 7), generator=g)
+    for t in range(n_tiles):
+        rows[t, counts[t]:] = 0.0
+    return rows, counts
+
+
+def _tile_worker(rank, world, port, n_tiles, R, q):
+    from skyeye.utils.tta import tile_shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    all_rows, all_counts = _fake_survivors(n_tiles, R)
+    lo, hi, per = tile_shard(n_tiles, rank, world)
+    rows = torch.zeros((per, R, 7))
+    counts = torch.zeros((per,), dtype=torch.int32)
+    rows[: hi - lo] = all_rows[lo:hi]
+    counts[: hi - lo] = all_counts[lo:hi]
+    g_rows, g_counts = all_gather_detections(rows, counts)
+    q.put((rank, g_rows.numpy(), g_counts.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_shards_cover_the_tiles_in_order():
+    from skyeye.utils.tta import tile_shard
+    for n, w in [(12, 8), (12, 2), (5, 4), (1, 8), (9, 1)]:
+        seen, pers = [], set()
+        for r in range(w):
+            lo, hi, per = tile_shard(n, r, w)
+            assert hi - lo <= per
+            seen += list(range(lo, hi))
+            pers.add(per)
+        assert seen == list(range(n)) and len(pers) == 1
+
+
+@pytest.mark.timeout(120)
+def test_tile_survivor_gather_world2_gloo_keeps_tile_order():
+    """After the gather every rank holds the survivor blocks of ALL tiles in row-major tile order (empty blocks where a rank
+    had fewer tiles than the common block count): dropping the empty blocks gives exactly the 1-process sequence."""
+    world, n_tiles, R = 2, 5, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n_tiles, R, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows1, counts1 = _fake_survivors(n_tiles, R)
+    from skyeye.utils.tta import tile_shard
+    per = tile_shard(n_tiles, 0, world)[2]
+    real = []                                            # positions of the real blocks inside the gathered buffer
+    for r in range(world):
+        lo, hi, _ = tile_shard(n_tiles, r, world)
+        real += [r * per + k for k in range(hi - lo)]
+    for rank, rows, counts in got:
+        assert rows.shape == (world * per, R, 7)
+        assert np.array_equal(rows[real].view(np.uint32), rows1.numpy().view(np.uint32))
+        assert np.array_equal(counts[real], counts1.numpy())
+        empty = sorted(set(range(world * per)) - set(real))
+        assert not counts[empty].any() and not rows[empty].any()

@@ -52,7 +52,7 @@ def scan(asm_path):
     for k, body in kernels.items():
         ins = [l.strip() for l in body if l.startswith("\t") and not l.strip().startswith((".", ";"))]
         for i, l in enumerate(ins):
-            if not re.match(r"buffer_store_dwordx[34]\b", l):
+            if not re.match(r"buffer_store_dwordx[234]\b", l):
                 continue
             ops = [t.strip() for t in l.split(None, 1)[1].split(",")]
             soff = ops[3].split()[0] if len(ops) > 3 else ""
