@@ -47,7 +47,11 @@ typedef enum {
 /* arithmetic type of the activations / MFMA operands (accumulation is always fp32) */
 typedef enum {
     SKY_F32 = 0,   /* exact mode: v_mfma_f32_16x16x4_f32, used for the 1e-4 parity gate */
-    SKY_BF16 = 1   /* production mode: v_mfma_f32_16x16x32_bf16 */
+    SKY_BF16 = 1,  /* production mode: v_mfma_f32_16x16x32_bf16 */
+    SKY_FP8 = 2    /* OCP e4m3fn weights (one scale per output channel) and activations (one calibrated scale per tensor, see
+                    * sky_calibrate): v_mfma_f32_16x16x32_fp8_fp8 / v_mfma_scale_f32_16x16x128_f8f6f4; the stem (pixel values) stays
+                    * bf16, accumulation, bias, SiLU, decode fp32.  Covers the convolutional graph (detector without attention heads).
+                    * The reference's only reduced-precision hook is model.half() (validate.py:195-197, detect.py:107-108). */
 } sky_dtype;
 
 /* element type / layout of caller buffers at the boundary */
@@ -178,6 +182,17 @@ int sky_output_info(const sky_handle* h, int index, int32_t* ndim, int64_t shape
 /* nn.Module.forward (detector.py:300-324 for the detector: outputs = [detections, raw_P3, raw_P4, raw_P5]). */
 int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs,
                 void* stream);
+
+/* fp8 engine (SKY_FP8) only: activation scales.  After sky_plan, run the planned graph once in bf16 on representative inputs (any
+ * batch size, same C, H, W) and give every fp8 workspace tensor the scale max|x| / 448.  sky_forward on an fp8 plan fails with
+ * SKY_ERR_STATE until this (or sky_scales_write) has been called.  Synchronises `stream`.  The scales belong to the plan:
+ * sky_num_scales / sky_scales_read / sky_scales_write save and restore them (one float per workspace buffer, 1 for non-fp8 ones),
+ * sky_packed_scales returns the per-output-channel weight scales of packed convolution i (ones for bf16 / fp32 weights). */
+int sky_calibrate(sky_handle* h, int n_inputs, const sky_buffer* inputs, void* stream);
+int sky_num_scales(const sky_handle* h);
+int sky_scales_read(sky_handle* h, float* scales_host, int n);
+int sky_scales_write(sky_handle* h, const float* scales_host, int n);
+int sky_packed_scales(sky_handle* h, int i, float* scales_host, size_t count);
 
 /*
  * non_max_suppression (metrics.py:361-457) on device.

@@ -65,6 +65,7 @@ struct TV {
     long off = 0;   // element offset (channel offset inside the pixel)
     int B = 0, H = 0, W = 0, C = 0, ld = 0;
     int ext = -1;   // 0..15 input slot, 16.. output slot
+    int dt = 0;     // element type (sky_dtype) of a workspace tensor
     bool valid() const { return buf >= 0 || ext >= 0; }
 };
 
@@ -86,6 +87,7 @@ struct Op {
     int s0 = -1, s1 = -1, s2 = -1;
     int nchunk = 0, R = 0;
     int f0 = -1, f1 = -1;  // fp32 device weights (index into Engine::fweights)
+    int cdt = 0;           // compute type of a convolution (= element type of its input; the packed weights have it too)
     int Ho = 0, Wo = 0;
     double flops = 0;
     int variant = 0;       // which conv kernel ran last (launch_conv)
@@ -102,6 +104,9 @@ struct Op {
 struct DevConv {
     void* w = nullptr;
     float* bias = nullptr;
+    float* mult = nullptr;           // fp8: per-output-channel input scale x weight scale (device, [rows]); set by apply_scales
+    std::vector<float> w_scale;      // fp8: per-output-channel weight scale (host, [rows])
+    int cdt = 0;                     // element type of the packed weights
     int Kpad = 0;
     size_t bytes = 0;
     // description for sky_packed_* (export of the engine's own weight file)
@@ -113,6 +118,9 @@ struct Buffer {
     size_t bytes = 0;
     int first = 1 << 30, last = -1;
     size_t offset = 0;
+    int dt = 0;          // element type (sky_dtype)
+    float scale = 1.0f;  // fp8 buffers: real value = stored value * scale (calibrated, sky_calibrate); 1 otherwise
+    int tie = -1;        // buffer whose scale this one must share (pooling / upsampling move bytes), -1 = itself
 };
 
 struct IoInfo {
@@ -146,8 +154,9 @@ struct Engine {
     unsigned opts = 0;      // PlanOpt bits, read from the environment once per sky_plan
     int n_cu = 256;         // compute units of cfg.device
 
-    int esize() const { return dtype == SKY_F32 ? 4 : 2; }
-    int epc() const { return dtype == SKY_F32 ? 4 : 8; }
+    bool calibrated = false;    // fp8: activation scales are set
+    int esize() const { return dtype_size(dtype); }
+    int epc() const { return 16 / dtype_size(dtype); }
     void free_plan()
     {
         for (void* p : owned) (void)hipFree(p);
@@ -177,6 +186,27 @@ static unsigned short f32_to_bf16(float f)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
+}
+
+// f32 -> e4m3fn, round to nearest even, saturating at +-448 (the device epilogues do the same: clamp, then v_cvt_pk_fp8_f32)
+static unsigned char f32_to_e4m3(float f)
+{
+    if (std::isnan(f)) return 0x7f;
+    const unsigned char sgn = std::signbit(f) ? 0x80 : 0;
+    float a = std::fabs(f);
+    if (a >= 448.0f) return sgn | 0x7e;
+    if (a < std::ldexp(1.0f, -10)) return sgn;                       // below half of the smallest subnormal (2^-9): zero
+    int ex;
+    (void)std::frexp(a, &ex);                                        // a = m * 2^ex, m in [0.5, 1)
+    int e = ex - 1;                                                  // a = (1.x) * 2^e
+    if (e < -6) e = -6;                                              // subnormal range: fixed exponent
+    const float q = std::ldexp(a, 3 - e);                            // in units of the mantissa step (8 steps per binade)
+    float r = std::nearbyint(q);                                     // FE_TONEAREST: ties to even
+    int mant = (int)r;
+    if (e == -6 && mant < 8) return sgn | (unsigned char)mant;       // subnormal (exponent field 0)
+    if (mant == 16) { mant = 8; ++e; }
+    if (e > 8 || (e == 8 && mant - 8 > 6)) return sgn | 0x7e;
+    return sgn | (unsigned char)(((e + 7) << 3) | (mant - 8));
 }
 
 // ------------------------------------------------------------------------------------------------ builder context
@@ -214,12 +244,22 @@ struct Ctx {
         e.bufs.push_back(b);
         return (int)e.bufs.size() - 1;
     }
-    TV new_tensor(int B, int H, int W_, int C)
+    TV new_tensor(int B, int H, int W_, int C, int dt = -1)
     {
         TV t;
         t.B = B; t.H = H; t.W = W_; t.C = C; t.ld = C;
-        t.buf = emit ? new_buf((size_t)B * H * W_ * C * e.esize()) : 0;
+        t.dt = dt < 0 ? e.dtype : dt;
+        t.buf = emit ? new_buf((size_t)B * H * W_ * C * dtype_size(t.dt)) : 0;
+        if (emit) e.bufs[t.buf].dt = t.dt;
         return t;
+    }
+    // the two buffers hold the same stored values (max-pooling, nearest upsampling move bytes): one scale for both
+    void tie_scales(int a, int b)
+    {
+        if (!emit || a < 0 || b < 0 || a == b) return;
+        auto root = [&](int i) { while (e.bufs[i].tie >= 0) i = e.bufs[i].tie; return i; };
+        const int ra = root(a), rb = root(b);
+        if (ra != rb) e.bufs[rb].tie = ra;
     }
     static TV slice(const TV& t, int c0, int C)
     {
@@ -263,11 +303,12 @@ struct Ctx {
         e.ops.push_back(op);
     }
 
-    void check_channels(int c, const char* what)
+    void check_channels(int c, const char* what, int dt = -1)
     {
-        if (c <= 0 || c % e.epc() != 0)
+        const int epc = 16 / dtype_size(dt < 0 ? e.dtype : dt);
+        if (c <= 0 || c % epc != 0)
             throw Error(SKY_ERR_INVALID, std::string(what) + ": channel count " + std::to_string(c) +
-                                             " is not a multiple of " + std::to_string(e.epc()) + " (16-byte vectors)");
+                                             " is not a multiple of " + std::to_string(epc) + " (16-byte vectors)");
     }
 
     // upload helpers -------------------------------------------------------------------------------------
@@ -289,13 +330,14 @@ struct Ctx {
         std::string bn;      // bn prefix ("" = none)
         std::string bias;    // bias name ("" = none)
     };
-    int pack_conv(const std::vector<ConvSrc>& srcs, int cin_real, int cin_store, int ks)
+    int pack_conv(const std::vector<ConvSrc>& srcs, int cin_real, int cin_store, int ks, int cdt = -1)
     {
         if (!emit) return -1;
+        if (cdt < 0) cdt = e.dtype;
         int cout = 0;
         for (auto& s : srcs) cout += (int)W(s.wname).shape[0];
         const int taps = ks * ks;
-        const int kstep = conv_k_step(e.dtype);
+        const int kstep = conv_k_step(cdt);
         const int K = taps * cin_store;
         const int Kpad = (K + kstep - 1) / kstep * kstep;
         const size_t rows = std::max(conv_weight_rows(cout), (size_t)(cout + 63) / 64 * 64);   // zero rows up to either kernel's N tile
@@ -324,17 +366,34 @@ struct Ctx {
         }
         DevConv d;
         d.Kpad = Kpad;
-        d.bytes = packed.size() * e.esize();
+        d.cdt = cdt;
+        d.bytes = packed.size() * dtype_size(cdt);
         d.rows = (int)rows; d.cout = cout; d.ks = ks; d.cin = cin_store;
         d.name = srcs.empty() ? std::string() : srcs[0].wname;
         SKY_HIP(hipMalloc(&d.w, d.bytes));
         e.owned.push_back(d.w);
-        if (e.dtype == SKY_F32) {
+        if (cdt == SKY_F32) {
             SKY_HIP(hipMemcpy(d.w, packed.data(), d.bytes, hipMemcpyHostToDevice));
-        } else {
+        } else if (cdt == SKY_BF16) {
             std::vector<unsigned short> h(packed.size());
             for (size_t i = 0; i < packed.size(); ++i) h[i] = f32_to_bf16(packed[i]);
             SKY_HIP(hipMemcpy(d.w, h.data(), d.bytes, hipMemcpyHostToDevice));
+        } else {
+            // fp8 (OCP e4m3fn): one scale per output channel, max |w| of the BN-folded row -> 448; bias stays fp32
+            std::vector<unsigned char> h(packed.size());
+            d.w_scale.assign(rows, 1.0f);
+            for (size_t r = 0; r < rows; ++r) {
+                const float* src = packed.data() + r * Kpad;
+                float amax = 0.0f;
+                for (int k = 0; k < Kpad; ++k) amax = std::max(amax, std::fabs(src[k]));
+                const float sc = amax > 0.0f ? amax / 448.0f : 1.0f;
+                d.w_scale[r] = sc;
+                for (int k = 0; k < Kpad; ++k) h[r * Kpad + k] = f32_to_e4m3(src[k] / sc);
+            }
+            SKY_HIP(hipMemcpy(d.w, h.data(), d.bytes, hipMemcpyHostToDevice));
+            SKY_HIP(hipMalloc(&d.mult, rows * sizeof(float)));
+            e.owned.push_back(d.mult);
+            SKY_HIP(hipMemcpy(d.mult, d.w_scale.data(), rows * sizeof(float), hipMemcpyHostToDevice));
         }
         SKY_HIP(hipMalloc(&d.bias, rows * sizeof(float)));
         e.owned.push_back(d.bias);
@@ -369,7 +428,7 @@ static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cou
     if (k != 1 && k != 3) throw Error(SKY_ERR_INVALID, p + ": kernel_size " + std::to_string(k) + " not supported (1 or 3)");
     c.need(p + "conv.weight", {cout, cin_real, k, k});
     need_bn(c, p + "bn.", cout);
-    c.check_channels(cin, (p + "in_channels").c_str());
+    c.check_channels(cin, (p + "in_channels").c_str(), x.dt);
     c.check_channels(cout, (p + "out_channels").c_str());
     if (x.C != cin) throw Error(SKY_ERR_SHAPE, p + ": input has " + std::to_string(x.C) + " channels, expected " + std::to_string(cin));
     const int Ho = out_dim(x.H, k, s), Wo = out_dim(x.W, k, s);
@@ -387,7 +446,8 @@ static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cou
     if (o.res) op.res = *o.res;
     op.cin = cin; op.cout = cout; op.ks = k; op.stride = s; op.act = act ? ACT_SILU : ACT_NONE; op.up2 = o.up2 ? 1 : 0;
     op.Ho = Ho; op.Wo = Wo;
-    op.wid = c.pack_conv({{p + "conv.weight", p + "bn.", ""}}, cin_real, cin, k);
+    op.cdt = x.dt;
+    op.wid = c.pack_conv({{p + "conv.weight", p + "bn.", ""}}, cin_real, cin, k, op.cdt);
     op.flops = 2.0 * x.B * Ho * Wo * (double)cout * k * k * cin_real;
     c.push(op);
     return y;
@@ -424,7 +484,8 @@ static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int 
         op.in = x; op.out = cat;
         op.cin = cin; op.cout = 2 * h; op.ks = 1; op.stride = 1; op.act = ACT_SILU;
         op.Ho = x.H; op.Wo = x.W;
-        op.wid = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}, {p + "cv2.conv.weight", p + "cv2.bn.", ""}}, cin, cin, 1);
+        op.cdt = x.dt;
+        op.wid = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}, {p + "cv2.conv.weight", p + "cv2.bn.", ""}}, cin, cin, 1, op.cdt);
         op.flops = 2.0 * x.B * x.H * x.W * (double)(2 * h) * cin;
         c.push(op);
     }
@@ -446,8 +507,8 @@ static TV spp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, cons
     o1.out_into = &s0;
     conv_block(c, p + "cv1.", x, cin, h, 1, 1, true, o1);
     // small maps (the 40 x 40 of a 1280-pixel frame): the three cascaded pools in one launch that reads cv1's slice once
-    const bool no_pyramid = (c.e.opts & OPT_NO_SPP_PYRAMID) != 0;
-    const int vec = c.e.dtype == 0 ? 4 : 8;
+    const bool no_pyramid = (c.e.opts & OPT_NO_SPP_PYRAMID) != 0 || c.e.dtype == SKY_FP8;
+    const int vec = c.e.epc();
     if (!no_pyramid && h % (2 * vec) == 0 && (long)x.H * x.W * 2 <= 4096) {
         Op op;
         op.kind = OP_MAXPOOL5;
@@ -456,7 +517,7 @@ static TV spp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, cons
         op.out = Ctx::slice(cat, h, 3 * h);
         c.push(op);
     } else {
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 3; ++i) {       // input and output slices share the concat buffer, hence its fp8 scale
             Op op;
             op.kind = OP_MAXPOOL5;
             op.in = Ctx::slice(cat, i * h, h);
@@ -531,14 +592,22 @@ static TV linear(Ctx& c, const std::string& wname, const std::string& bname, con
     if (res) op.res = *res;
     op.cin = cin; op.cout = cout; op.ks = 1; op.stride = 1; op.act = act;
     op.Ho = x.H; op.Wo = x.W;
-    op.wid = c.pack_conv({{wname, "", bname}}, cin, cin, 1);
+    op.cdt = x.dt;
+    op.wid = c.pack_conv({{wname, "", bname}}, cin, cin, 1, op.cdt);
     op.flops = 2.0 * x.B * x.H * x.W * (double)cout * cin;
     c.push(op);
     return y;
 }
 
+static void no_fp8(Ctx& c, const char* what)
+{
+    if (c.e.dtype == SKY_FP8)
+        throw Error(SKY_ERR_INVALID, std::string(what) + " is not built for the fp8 engine (SKY_FP8 covers the convolutional detector; use SKY_BF16)");
+}
+
 static TV layernorm(Ctx& c, const std::string& p, const TV& x, int C)
 {
+    no_fp8(c, "LayerNorm / TransformerLayer");
     c.need(p + "weight", {C});
     c.need(p + "bias", {C});
     TV y = c.new_tensor(x.B, x.H, x.W, C);
@@ -552,6 +621,7 @@ static TV layernorm(Ctx& c, const std::string& p, const TV& x, int C)
 
 static TV attention_core(Ctx& c, const TV& qkv, int C, int heads, float scale, int bias_f, int mask_ext, int nW, int win = 0)
 {
+    no_fp8(c, "attention");
     const int d = C / heads;
     if (C % heads || (d != 8 && d != 16 && d != 32 && d != 64 && d != 128))
         throw Error(SKY_ERR_INVALID, "attention head dimension " + std::to_string(d) + " not supported (8, 16, 32, 64, 128)");
@@ -632,6 +702,7 @@ static TV windowed_attention_map(Ctx& c, const std::string& p, const TV& x, int 
 static TV cross_layer_attention(Ctx& c, const std::string& p, const TV& q, const TV& k, int Cq, int Ck, int Cout, int heads, int region,
                                 const TV* res = nullptr, const TV* out_into = nullptr)
 {
+    no_fp8(c, "CrossLayerAttention");
     if (Cq % heads) throw Error(SKY_ERR_INVALID, p + ": query_channels must be divisible by heads");
     TV Q = linear(c, p + "query_projection.weight", p + "query_projection.bias", q, Cq, Cq, ACT_NONE, true);
     // key | value projections as one GEMM with N = 2*Cq
@@ -648,7 +719,8 @@ static TV cross_layer_attention(Ctx& c, const std::string& p, const TV& q, const
         op.in = k; op.out = KV;
         op.cin = Ck; op.cout = 2 * Cq; op.ks = 1; op.stride = 1; op.act = ACT_NONE;
         op.Ho = k.H; op.Wo = k.W;
-        op.wid = c.pack_conv({{p + "key_projection.weight", "", p + "key_projection.bias"}, {p + "value_projection.weight", "", p + "value_projection.bias"}}, Ck, Ck, 1);
+        op.cdt = k.dt;
+        op.wid = c.pack_conv({{p + "key_projection.weight", "", p + "key_projection.bias"}, {p + "value_projection.weight", "", p + "value_projection.bias"}}, Ck, Ck, 1, op.cdt);
         op.flops = 2.0 * k.B * k.H * k.W * (double)(2 * Cq) * Ck;
         c.push(op);
     }
@@ -678,9 +750,11 @@ struct BackboneOut {
 static TV import_focus(Ctx& c, int ext, int B, int C, int H, int W)
 {
     if ((H & 1) || (W & 1)) throw Error(SKY_ERR_SHAPE, "FocusBlock needs even H and W");
-    const int epc = c.e.epc();
+    // the fp8 engine keeps the stem in bf16: pixel values i / 255 have 8 significant bits, e4m3 has 4
+    const int dt = c.e.dtype == SKY_FP8 ? (int)SKY_BF16 : c.e.dtype;
+    const int epc = std::max(16 / dtype_size(dt), c.e.dtype == SKY_FP8 ? 16 : 1);
     const int Cs = (4 * C + epc - 1) / epc * epc;
-    TV t = c.new_tensor(B, H / 2, W / 2, Cs);
+    TV t = c.new_tensor(B, H / 2, W / 2, Cs, dt);
     Op op;
     op.kind = OP_IMPORT;
     op.in.ext = ext; op.out = t; op.s2d = 1; op.src_c = C; op.src_h = H; op.src_w = W;
@@ -789,6 +863,7 @@ static void neck(Ctx& c, const std::string& p, const NeckSlots& n, int c3, int c
             TV t = conv_block(c, p + name, x, cin, cout, 1, 1, true);
             Op u;
             u.kind = OP_UPSAMPLE; u.in = t; u.out = slot;
+            c.tie_scales(t.buf, slot.buf);
             c.push(u);
         }
     };
@@ -834,7 +909,8 @@ static void head(Ctx& c, const std::string& p, const TV* feats, int nl, int nc, 
         op.det_ext = 16 + first_out;
         op.det_rows = rows; op.det_off = off;
         op.stride_px = (float)std::max((double)in_h / f.H, (double)in_w / f.W);          // detector.py:107-109
-        op.wid = c.pack_conv({{l + "weight", "", l + "bias"}}, f.C, f.C, 1);
+        op.cdt = f.dt;
+        op.wid = c.pack_conv({{l + "weight", "", l + "bias"}}, f.C, f.C, 1, op.cdt);
         op.flops = 2.0 * f.B * f.H * f.W * (double)(na * no) * f.C;
         c.push(op);
         off += (long)na * f.H * f.W;
@@ -1080,13 +1156,24 @@ static void* tv_ptr(const Engine& e, const TV& t, const sky_buffer* ins, int n_i
         return ins[t.ext].data;
     }
     if (t.buf < 0) return nullptr;
-    return e.arena + e.bufs[t.buf].offset + (size_t)t.off * e.esize();
+    return e.arena + e.bufs[t.buf].offset + (size_t)t.off * dtype_size(t.dt);
+}
+
+// scale of the (fp8) buffer a view lives in: real value = stored value * scale; 1 for bf16 / fp32 tensors and caller buffers
+static float tv_scale(const Engine& e, const TV& t)
+{
+    if (t.buf < 0 || t.dt != SKY_FP8) return 1.0f;
+    int i = t.buf;
+    while (e.bufs[i].tie >= 0) i = e.bufs[i].tie;
+    return e.bufs[i].scale;
 }
 
 static void* buf_ptr(const Engine& e, int buf) { return buf < 0 ? nullptr : (void*)(e.arena + e.bufs[buf].offset); }
 
+// amax (calibration pass of the fp8 engine's bf16 twin): device array, one slot per workspace buffer, max |x| over every
+// tensor an op writes there
 static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* outs, int n_out, hipStream_t s,
-                hipEvent_t* marks = nullptr)
+                hipEvent_t* marks = nullptr, unsigned int* amax = nullptr)
 {
     const sky_config& cf = e.cfg;
     int op_index = 0;
@@ -1118,9 +1205,10 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         t.ldo = nx.out.ld; t.ks = 3; t.stride = 1; t.pad = 1; t.Kpad = e.convs[nx.wid].Kpad; t.up2 = nx.up2; t.head = nx.head;
                         t.M = nx.in.B * nx.Ho * nx.Wo;
                         t.opts = e.opts; t.device = cf.device; t.n_cu = e.n_cu;
-                        const double oext = (((double)t.M - 1.0) * nx.out.ld + nx.cout) * e.esize();
+                        t.out_dt = nx.out.dt;
+                        const double oext = (((double)t.M - 1.0) * nx.out.ld + nx.cout) * dtype_size(nx.out.dt);
                         t.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
-                        if (conv_accepts_raw(e.dtype, t)) {
+                        if (conv_accepts_raw(nx.cdt, t)) {
                             raw_src = src.data;
                             raw_mode = src.dtype == SKY_IO_U8 ? 1 : 2;
                             op.variant = 9100;
@@ -1128,13 +1216,13 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         }
                     }
                 }
-                SKY_HIP(launch_import(e.dtype, src.data, src.dtype == SKY_IO_U8, op.force_nhwc || src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
-                                      op.out.B, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld, op.s2d, src.dtype == SKY_IO_U8, s));
+                SKY_HIP(launch_import(op.out.dt, src.data, src.dtype == SKY_IO_U8, op.force_nhwc || src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                      op.out.B, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld, op.s2d, src.dtype == SKY_IO_U8, s, 1.0f / tv_scale(e, op.out)));
                 break;
             }
             case OP_EXPORT:
-                SKY_HIP(launch_export(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (float*)tv_ptr(e, op.out, ins, n_in, outs, n_out),
-                                      op.in.B, op.in.C, op.in.H, op.in.W, s));
+                SKY_HIP(launch_export(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (float*)tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                                      op.in.B, op.in.C, op.in.H, op.in.W, s, tv_scale(e, op.in)));
                 break;
             case OP_CONV: {
                 ConvArgs a;
@@ -1150,9 +1238,12 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 a.act = op.act; a.up2 = op.up2;
                 a.M = op.in.B * op.Ho * op.Wo;
                 {
-                    const double ext = ((double)op.in.B * op.in.H * op.in.W - 1.0) * op.in.ld * e.esize() + (double)op.cin * e.esize();
+                    const int ies = dtype_size(op.cdt);
+                    const double ext = ((double)op.in.B * op.in.H * op.in.W - 1.0) * op.in.ld * ies + (double)op.cin * ies;
                     a.in_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;   // offsets are computed in int32
                 }
+                a.mult = d.mult;                       // fp8 operands only (nullptr otherwise)
+                a.out_inv_scale = 1.0f; a.res_scale = 1.0f; a.out_dt = -1;
                 if (op.head) {
                     a.head = 1;
                     TV r; r.ext = op.raw_ext;
@@ -1167,12 +1258,17 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     a.out = tv_ptr(e, op.out, ins, n_in, outs, n_out);
                     a.ldo = op.out.ld;
                     const double opix = (double)a.M * (op.up2 ? 4.0 : 1.0) - 1.0;
-                    const double oext = (opix * op.out.ld + op.cout) * e.esize();
+                    const int oes = dtype_size(op.out.dt);
+                    a.out_dt = op.out.dt;
+                    a.out_inv_scale = 1.0f / tv_scale(e, op.out);
+                    const double oext = (opix * op.out.ld + op.cout) * oes;
                     a.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
                     if (op.res.valid()) {
                         a.res = tv_ptr(e, op.res, ins, n_in, outs, n_out);
                         a.ldr = op.res.ld;
-                        const double rext = (((double)a.M - 1.0) * op.res.ld + op.cout) * e.esize();
+                        if (op.res.dt != op.out.dt) throw Error(SKY_ERR_INVALID, "residual and output element types differ");
+                        a.res_scale = tv_scale(e, op.res);
+                        const double rext = (((double)a.M - 1.0) * op.res.ld + op.cout) * oes;
                         a.res_bytes = rext < 2147483000.0 ? (unsigned)rext : 0u;
                     }
                 }
@@ -1183,38 +1279,38 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     a.f2_out = tv_ptr(e, f.out, ins, n_in, outs, n_out);
                     a.f2_cin = f.cin; a.f2_cout = f.cout; a.f2_ldo = f.out.ld; a.f2_act = f.act;
                     a.f2_koff = (int)(f.in.off - op.out.off);
-                    const double fext = (((double)a.M - 1.0) * f.out.ld + f.cout) * e.esize();
+                    const double fext = (((double)a.M - 1.0) * f.out.ld + f.cout) * dtype_size(f.out.dt);
                     a.f2_out_bytes = fext < 2147483000.0 ? (unsigned)fext : 0u;
                 }
                 int fused = 0;
-                SKY_HIP(launch_conv(e.dtype, a, s, &op.variant, &fused));
+                SKY_HIP(launch_conv(op.cdt, a, s, &op.variant, &fused));
                 took_next = fused != 0;
                 break;
             }
             case OP_MAXPOOL5:
                 if (op.win == 3) {
-                    SKY_HIP(launch_spp_pyramid(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                    SKY_HIP(launch_spp_pyramid(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                                op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, op.in.C, s));
                     break;
                 }
-                SKY_HIP(launch_maxpool5(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                SKY_HIP(launch_maxpool5(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                         op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, s));
                 break;
             case OP_UPSAMPLE:
-                SKY_HIP(launch_upsample(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
+                SKY_HIP(launch_upsample(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, tv_ptr(e, op.out, ins, n_in, outs, n_out),
                                         op.out.ld, op.in.B, op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, s));
                 break;
             case OP_CA_REDUCE:
-                SKY_HIP(launch_ca_reduce(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, op.in.B, op.in.H * op.in.W, op.in.C,
-                                         op.nchunk, (float*)buf_ptr(e, op.s0), s));
+                SKY_HIP(launch_ca_reduce(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, op.in.B, op.in.H * op.in.W, op.in.C,
+                                         op.nchunk, (float*)buf_ptr(e, op.s0), s, tv_scale(e, op.in)));
                 break;
             case OP_CA_MLP:
                 SKY_HIP(launch_ca_mlp((const float*)buf_ptr(e, op.s0), op.in.B, op.in.H * op.in.W, op.in.C, op.nchunk, op.R, e.fweights[op.f0],
                                       e.fweights[op.f1], (float*)buf_ptr(e, op.s1), s));
                 break;
             case OP_SA_STATS:
-                SKY_HIP(launch_sa_stats(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (const float*)buf_ptr(e, op.s0), op.in.B,
-                                        op.in.H * op.in.W, op.in.C, (float*)buf_ptr(e, op.s1), s));
+                SKY_HIP(launch_sa_stats(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (const float*)buf_ptr(e, op.s0), op.in.B,
+                                        op.in.H * op.in.W, op.in.C, (float*)buf_ptr(e, op.s1), s, tv_scale(e, op.in)));
                 break;
             case OP_SA_GATE:
                 SKY_HIP(launch_sa_gate((const float*)buf_ptr(e, op.s0), e.fweights[op.f0], op.in.B, op.in.H, op.in.W, (float*)buf_ptr(e, op.s1), s));
@@ -1247,11 +1343,14 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 break;
             }
             case OP_SCALE:
-                SKY_HIP(launch_scale(e.dtype, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (const float*)buf_ptr(e, op.s0),
+                SKY_HIP(launch_scale(op.in.dt, tv_ptr(e, op.in, ins, n_in, outs, n_out), op.in.ld, (const float*)buf_ptr(e, op.s0),
                                      (const float*)buf_ptr(e, op.s1), tv_ptr(e, op.out, ins, n_in, outs, n_out), op.out.ld, op.in.B,
-                                     op.in.H * op.in.W, op.in.C, s));
+                                     op.in.H * op.in.W, op.in.C, s, tv_scale(e, op.in), 1.0f / tv_scale(e, op.out)));
                 break;
         }
+        if (amax && op.out.buf >= 0 && op.out.dt != SKY_FP8 && op.out.B > 0)
+            SKY_HIP(launch_amax(op.out.dt, tv_ptr(e, op.out, ins, n_in, outs, n_out), op.out.ld, (long)op.out.B * op.out.H * op.out.W, op.out.C,
+                                amax + op.out.buf, s));
         ++op_index;
         if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
     }
@@ -1331,6 +1430,7 @@ static void plan(Engine& e, const Geometry& g)
 {
     e.free_plan();
     e.opts = read_plan_opts();
+    if (e.dtype == SKY_FP8) e.opts &= ~(unsigned)OPT_FUSE;
     {
         hipDeviceProp_t prop;
         SKY_HIP(hipGetDeviceProperties(&prop, e.cfg.device));
@@ -1346,11 +1446,93 @@ static void plan(Engine& e, const Geometry& g)
     SKY_HIP(hipMalloc(&e.zero_page, 256));
     SKY_HIP(hipMemset(e.zero_page, 0, 256));
     for (const Op& op : e.ops) {
-        auto bytes = [&](const TV& t) { return t.valid() ? (double)t.B * t.H * t.W * t.C * e.esize() : 0.0; };
+        auto bytes = [&](const TV& t) { return t.valid() ? (double)t.B * t.H * t.W * t.C * (t.buf >= 0 ? dtype_size(t.dt) : e.esize()) : 0.0; };
         e.act_bytes += bytes(op.in) + bytes(op.out) + bytes(op.res);
     }
     e.planned = true;
     e.weights_dirty = false;
+    e.calibrated = e.dtype != SKY_FP8;
+}
+
+// fp8: per-output-channel multipliers of every fp8 convolution = scale of its input tensor x weight scale of the channel
+static void apply_scales(Engine& e)
+{
+    for (const Op& op : e.ops) {
+        if (op.kind != OP_CONV || op.cdt != SKY_FP8) continue;
+        DevConv& d = e.convs[op.wid];
+        const float si = tv_scale(e, op.in);
+        std::vector<float> m(d.rows);
+        for (int r = 0; r < d.rows; ++r) m[r] = si * d.w_scale[r];
+        SKY_HIP(hipMemcpy(d.mult, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+}
+
+static Geometry geometry_of(int n_inputs, const sky_buffer* in)
+{
+    Geometry g;
+    g.n = n_inputs;
+    for (int i = 0; i < n_inputs; ++i) {
+        g.ndim[i] = in[i].ndim;
+        for (int k = 0; k < 5; ++k) g.shape[i][k] = k < in[i].ndim ? in[i].shape[k] : 0;
+        // boundary tensors are described logically as [B, C, H, W] whatever their memory layout
+    }
+    return g;
+}
+
+// Activation scales of the fp8 engine.  The same graph is planned once more as a bf16 "twin" on the calibration inputs (any batch
+// size; the builder creates the workspace buffers in the same order for every dtype and geometry), run with an amax reduction
+// behind every launch, and every fp8 buffer gets scale = max |x| / 448: the largest calibration value maps to the largest e4m3.
+static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStream_t s)
+{
+    if (e.dtype != SKY_FP8) throw Error(SKY_ERR_STATE, "sky_calibrate: only the fp8 engine has activation scales");
+    if (!e.planned) throw Error(SKY_ERR_STATE, "sky_calibrate before sky_plan");
+    Engine tw;
+    tw.cfg = e.cfg;
+    tw.cfg.dtype = SKY_BF16;
+    tw.dtype = SKY_BF16;
+    tw.weights = e.weights;
+    plan(tw, geometry_of(n_inputs, inputs));
+    if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");
+    std::vector<sky_buffer> outs(tw.out_info.size());
+    std::vector<void*> tmp;
+    std::vector<char> optional(outs.size(), 0);
+    for (const Op& op : tw.ops)
+        if (op.kind == OP_CONV && op.head && op.raw_ext >= 16 && op.raw_ext - 16 < (int)outs.size()) optional[op.raw_ext - 16] = 1;
+    unsigned int* amax = nullptr;
+    auto cleanup = [&] {
+        for (void* p : tmp) (void)hipFree(p);
+        if (amax) (void)hipFree(amax);
+    };
+    try {
+        for (size_t i = 0; i < outs.size(); ++i) {
+            memset(&outs[i], 0, sizeof(sky_buffer));
+            if (optional[i]) continue;
+            size_t n = 1;
+            for (int k = 0; k < tw.out_info[i].ndim; ++k) n *= (size_t)tw.out_info[i].shape[k];
+            void* p = nullptr;
+            SKY_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+            tmp.push_back(p);
+            outs[i].data = p;
+        }
+        SKY_HIP(hipMalloc(&amax, tw.bufs.size() * sizeof(unsigned int)));
+        SKY_HIP(hipMemsetAsync(amax, 0, tw.bufs.size() * sizeof(unsigned int), s));
+        run(tw, inputs, n_inputs, outs.data(), (int)outs.size(), s, nullptr, amax);
+        std::vector<float> host(tw.bufs.size());
+        SKY_HIP(hipMemcpyAsync(host.data(), amax, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        SKY_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < e.bufs.size(); ++i) e.bufs[i].scale = (e.bufs[i].dt == SKY_FP8 && host[i] > 0.0f) ? host[i] / 448.0f : 1.0f;
+        for (size_t i = 0; i < e.bufs.size(); ++i) {        // tied buffers: the root carries the larger range
+            int r = (int)i;
+            while (e.bufs[r].tie >= 0) r = e.bufs[r].tie;
+            if (r != (int)i) e.bufs[r].scale = std::max(e.bufs[r].scale, e.bufs[i].scale);
+        }
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+    apply_scales(e);
+    e.calibrated = true;
 }
 
 }  // namespace sky
@@ -1399,7 +1581,7 @@ int sky_create(const sky_config* cfg, sky_handle** out)
         h = new sky_handle();
         h->e.cfg = *cfg;
         h->e.dtype = cfg->dtype;
-        if (cfg->dtype != SKY_F32 && cfg->dtype != SKY_BF16) throw Error(SKY_ERR_INVALID, "unknown dtype");
+        if (cfg->dtype != SKY_F32 && cfg->dtype != SKY_BF16 && cfg->dtype != SKY_FP8) throw Error(SKY_ERR_INVALID, "unknown dtype");
         sky_config& c = h->e.cfg;
         if (c.base_channels <= 0) c.base_channels = 64;
         if (c.depth_multiple <= 0) c.depth_multiple = 1.0f;
@@ -1457,13 +1639,7 @@ int sky_plan(sky_handle* h, int n_inputs, const sky_buffer* in)
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(SKY_ERR_NO_DEVICE, "no HIP device visible: the HIP engine cannot run (there is no CPU fallback)");
         DeviceGuard dg(h->e.cfg.device);
-        Geometry g;
-        g.n = n_inputs;
-        for (int i = 0; i < n_inputs; ++i) {
-            g.ndim[i] = in[i].ndim;
-            for (int k = 0; k < 5; ++k) g.shape[i][k] = k < in[i].ndim ? in[i].shape[k] : 0;
-            // boundary tensors are described logically as [B, C, H, W] whatever their memory layout
-        }
+        const Geometry g = geometry_of(n_inputs, in);
         plan(h->e, g);
         h->geom = g;
     });
@@ -1484,6 +1660,7 @@ static void check_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs,
 {
     if (!h->e.planned) throw Error(SKY_ERR_STATE, "sky_forward before sky_plan");
     if (h->e.weights_dirty) throw Error(SKY_ERR_STATE, "weights changed after sky_plan: call sky_plan again");
+    if (!h->e.calibrated) throw Error(SKY_ERR_STATE, "fp8 engine without activation scales: call sky_calibrate (or sky_scales_write) after sky_plan");
     if (n_inputs != h->geom.n) throw Error(SKY_ERR_SHAPE, "sky_forward: input count differs from the plan");
     if (n_outputs != (int)h->e.out_info.size()) throw Error(SKY_ERR_SHAPE, "sky_forward: expected " + std::to_string(h->e.out_info.size()) + " outputs");
     for (int i = 0; i < n_inputs; ++i) {
@@ -1588,7 +1765,7 @@ int sky_op_bytes(const sky_handle* h, int index, double* bytes)
     if (!h || !bytes || index < 0 || index >= (int)h->e.ops.size()) return SKY_ERR_INVALID;
     const Op& op = h->e.ops[index];
     const int es = h->e.esize();
-    auto sz = [&](const TV& t, int esz) { return (t.buf >= 0 || t.ext >= 0) && t.B ? (double)t.B * t.H * t.W * t.C * esz : 0.0; };
+    auto sz = [&](const TV& t, int esz) { return (t.buf >= 0 || t.ext >= 0) && t.B ? (double)t.B * t.H * t.W * t.C * (t.buf >= 0 ? dtype_size(t.dt) : esz) : 0.0; };
     double b = sz(op.in, es) + sz(op.out, es) + sz(op.res, es) + sz(op.in2, es);
     if (op.kind == OP_CONV && op.head) b += 2.0 * op.in.B * op.Ho * op.Wo * (double)op.cout * 4;   // raw + decoded, fp32
     if (op.kind == OP_IMPORT) b += (double)op.out.B * op.src_c * op.src_h * op.src_w;                // uint8 frames (4x for fp32 input)
@@ -1621,7 +1798,7 @@ int sky_packed_info(const sky_handle* h, int i, sky_packed_desc* out)
     memset(out, 0, sizeof(*out));
     snprintf(out->name, sizeof(out->name), "%s", d.name.c_str());
     out->rows = d.rows; out->cout = d.cout; out->kpad = d.Kpad; out->kernel_size = d.ks; out->cin = d.cin;
-    out->dtype = h->e.dtype;
+    out->dtype = d.cdt;
     return SKY_OK;
 }
 
@@ -1641,6 +1818,63 @@ int sky_packed_read(sky_handle* h, int i, void* weights_host, size_t weight_byte
             if (bias_count < (size_t)d.rows) throw Error(SKY_ERR_INVALID, "sky_packed_read: bias buffer too small");
             SKY_HIP(hipMemcpy(bias_host, d.bias, (size_t)d.rows * sizeof(float), hipMemcpyDeviceToHost));
         }
+    });
+}
+
+int sky_packed_scales(sky_handle* h, int i, float* scales_host, size_t count)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!h->e.planned) throw Error(SKY_ERR_STATE, "sky_packed_scales: plan the graph first");
+        if (i < 0 || i >= (int)h->e.convs.size() || !scales_host) throw Error(SKY_ERR_INVALID, "sky_packed_scales: bad argument");
+        const DevConv& d = h->e.convs[i];
+        if (count < (size_t)d.rows) throw Error(SKY_ERR_INVALID, "sky_packed_scales: buffer too small");
+        for (int r = 0; r < d.rows; ++r) scales_host[r] = d.w_scale.empty() ? 1.0f : d.w_scale[r];
+    });
+}
+
+int sky_calibrate(sky_handle* h, int n_inputs, const sky_buffer* inputs, void* stream)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (n_inputs != h->geom.n) throw Error(SKY_ERR_SHAPE, "sky_calibrate: input count differs from the plan");
+        for (int i = 0; i < n_inputs; ++i)
+            if (!inputs[i].data) throw Error(SKY_ERR_INVALID, "sky_calibrate: null input");
+        DeviceGuard dg(h->e.cfg.device);
+        calibrate(h->e, n_inputs, inputs, (hipStream_t)stream);
+    });
+}
+
+int sky_num_scales(const sky_handle* h) { return h && h->e.planned ? (int)h->e.bufs.size() : 0; }
+
+int sky_scales_read(sky_handle* h, float* scales_host, int n)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!h->e.planned || !scales_host || n < (int)h->e.bufs.size()) throw Error(SKY_ERR_INVALID, "sky_scales_read: plan first / buffer too small");
+        for (size_t i = 0; i < h->e.bufs.size(); ++i) {
+            TV t; t.buf = (int)i; t.dt = h->e.bufs[i].dt;
+            scales_host[i] = tv_scale(h->e, t);
+        }
+    });
+}
+
+int sky_scales_write(sky_handle* h, const float* scales_host, int n)
+{
+    if (!h) return SKY_ERR_INVALID;
+    return guarded(h, [&] {
+        if (!h->e.planned || !scales_host || n != (int)h->e.bufs.size()) throw Error(SKY_ERR_INVALID, "sky_scales_write: plan first; one scale per workspace buffer (sky_num_scales)");
+        if (h->e.dtype != SKY_FP8) throw Error(SKY_ERR_STATE, "sky_scales_write: only the fp8 engine has activation scales");
+        for (int i = 0; i < n; ++i)
+            if (!(scales_host[i] > 0.0f)) throw Error(SKY_ERR_INVALID, "sky_scales_write: scales must be positive");
+        DeviceGuard dg(h->e.cfg.device);
+        for (int i = 0; i < n; ++i) {
+            int r = i;
+            while (h->e.bufs[r].tie >= 0) r = h->e.bufs[r].tie;
+            if (h->e.bufs[i].dt == SKY_FP8) h->e.bufs[r].scale = scales_host[i];
+        }
+        apply_scales(h->e);
+        h->e.calibrated = true;
     });
 }
 

@@ -19,14 +19,11 @@
 //   * blockIdx is remapped so that consecutive logical tiles (same pixel rows, all N tiles) land on one XCD.
 #include "sky_kernels.h"
 
-#include <hip/hip_bf16.h>
+#include "conv_frag.h"
+
 #include <stdlib.h>
 
 namespace sky {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 __device__ __forceinline__ float act_apply(float v, int act)
 {
@@ -47,6 +44,10 @@ template <>
 struct TypeInfo<__bf16> {
     static constexpr int EPC = 8;
 };
+template <>
+struct TypeInfo<fp8_t> {
+    static constexpr int EPC = 16;
+};
 
 template <typename T>
 __device__ __forceinline__ void mma_chunk(const u32x4_t& wf, const u32x4_t& pf, f32x4_t& acc);
@@ -59,6 +60,12 @@ __device__ __forceinline__ void mma_chunk<__bf16>(const u32x4_t& wf, const u32x4
 }
 
 template <>
+__device__ __forceinline__ void mma_chunk<fp8_t>(const u32x4_t& wf, const u32x4_t& pf, f32x4_t& acc)
+{
+    S1<fp8_t>::mma(wf, pf, acc);
+}
+
+template <>
 __device__ __forceinline__ void mma_chunk<float>(const u32x4_t& wf, const u32x4_t& pf, f32x4_t& acc)
 {
 #pragma unroll
@@ -66,9 +73,10 @@ __device__ __forceinline__ void mma_chunk<float>(const u32x4_t& wf, const u32x4_
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[j]), __uint_as_float(pf[j]), acc, 0, 0, 0);
 }
 
-template <typename T, int WM, int WN, int MF, int NF>
+template <typename T, int WM, int WN, int MF, int NF, typename TO = T>
 __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs a)
 {
+    constexpr bool QS = sizeof(T) == 1;   // fp8 operands: acc * mult[cout] (input scale x weight scale) before the bias
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * MF * 16;
     constexpr int BN = WN * NF * 16;
@@ -245,9 +253,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         auto element = [&](int an, int ml, int o, float aw, float ah, float& rawv, float& detv) {
 #pragma clang fp contract(off)
             const int n = an * a.no + o;
-            const float v = ot[ml * OP + n] + a.bias[n];
+            const float v = (QS ? ot[ml * OP + n] * (a.mult ? a.mult[n] : 1.0f) : ot[ml * OP + n]) + a.bias[n];
             rawv = v;
-            const float s = head_sigmoid<sizeof(T) == 2>(v);
+            const float s = head_sigmoid<sizeof(T) <= 2>(v);
             float d;
             if (o == 0) d = (s * 2.0f - 0.5f + gx[ml]) * a.stride_px;
             else if (o == 1) d = (s * 2.0f - 0.5f + gx[BM + ml]) * a.stride_px;
@@ -314,7 +322,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             const int ml = idx / BN, nl = idx - ml * BN;
             const int m = m0 + ml, n = n0 + nl;
             if (m >= a.M || n >= a.Cout) continue;
-            const float v = ot[ml * OP + nl] + a.bias[n];
+            const float v = (QS ? ot[ml * OP + nl] * (a.mult ? a.mult[n] : 1.0f) : ot[ml * OP + nl]) + a.bias[n];
             const int an = n / a.no, o = n - an * a.no;
             const int x = m % a.Wo;
             const int t = m / a.Wo;
@@ -322,7 +330,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             const int b = t / a.Ho;
             const long cell = ((long)(b * a.na + an) * a.Ho + y) * a.Wo + x;
             if (a.raw) a.raw[cell * a.no + o] = v;
-            const float s = head_sigmoid<sizeof(T) == 2>(v);
+            const float s = head_sigmoid<sizeof(T) <= 2>(v);
             float d;
             if (o == 0) d = (s * 2.0f - 0.5f + (float)x) * a.stride_px;
             else if (o == 1) d = (s * 2.0f - 0.5f + (float)y) * a.stride_px;
@@ -334,44 +342,57 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         return;
     }
 
-    const bool wide = (sizeof(T) == 2) && !a.out_f32;   // 8 channels per 16-byte store, else 4
-    const int V = wide ? 8 : 4;
-    const int groups = BN / V;
-    for (int idx = tid; idx < BM * groups; idx += NT) {
-        const int ml = idx / groups, g = idx - ml * groups;
-        const int m = m0 + ml, n = n0 + g * V;
-        if (m >= a.M || n >= a.Cout) continue;
-        float v[8];
-        const float* src = ot + ml * OP + g * V;
+    if (a.out_f32 || sizeof(TO) == 4) {                 // fp32 output (exact engine; channel counts are multiples of 4): 4 channels per 16-byte store
+        constexpr int V = 4;
+        constexpr int groups = BN / V;
+        for (int idx = tid; idx < BM * groups; idx += NT) {
+            const int ml = idx / groups, g = idx - ml * groups;
+            const int m = m0 + ml, n = n0 + g * V;
+            if (m >= a.M || n >= a.Cout) continue;
+            float v[V];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (e < V) v[e] = act_apply(src[e] + a.bias[n + e], a.act);
-        if (a.res) {
-            if (sizeof(T) == 2) {
-                if (wide) {
-                    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.res) + (long)m * a.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += bf16_bits_to_f32(r[e] & 0xffffu);
-                        v[2 * e + 1] += bf16_bits_to_f32(r[e] >> 16);
-                    }
-                } else {
-                    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.res) + (long)m * a.ldr + n);
-                    v[0] += bf16_bits_to_f32(r.x & 0xffffu);
-                    v[1] += bf16_bits_to_f32(r.x >> 16);
-                    v[2] += bf16_bits_to_f32(r.y & 0xffffu);
-                    v[3] += bf16_bits_to_f32(r.y >> 16);
-                }
-            } else {
+            for (int e = 0; e < V; ++e)
+                v[e] = act_apply((QS ? ot[ml * OP + g * V + e] * (a.mult ? a.mult[n + e] : 1.0f) : ot[ml * OP + g * V + e]) + a.bias[n + e], a.act);
+            if (a.res) {
                 const f32x4_t r = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(a.res) + (long)m * a.ldr + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += r[e];
             }
+            long p0 = m;
+            int rep = 1;
+            long dstep_y = 0;
+            if (a.up2) {
+                const int x = m % a.Wo;
+                const int t = m / a.Wo;
+                const int y = t % a.Ho;
+                const int b = t / a.Ho;
+                p0 = ((long)(b * 2 * a.Ho + 2 * y)) * (2 * a.Wo) + 2 * x;
+                rep = 4;
+                dstep_y = 2 * a.Wo;
+            }
+            for (int r = 0; r < rep; ++r) {
+                const long p = p0 + (r & 1) + (r >> 1) * dstep_y;
+                *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.out) + p * a.ldo + n) = f32x4_t{v[0], v[1], v[2], v[3]};
+            }
         }
+        return;
+    }
+    // output in TO: 8 channels per item (16 bytes of bf16, 2 x 16 of fp32, 8 of fp8) through the same Out8 pack the other kernels use
+    constexpr int V = 8;
+    constexpr int groups = BN / V;
+    for (int idx = tid; idx < BM * groups; idx += NT) {
+        const int ml = idx / groups, g = idx - ml * groups;
+        const int m = m0 + ml, n = n0 + g * V;
+        if (m >= a.M || n >= a.Cout) continue;
+        float v[V];
+        const float* src = ot + ml * OP + g * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = act_apply((QS ? src[e] * (a.mult ? a.mult[n + e] : 1.0f) : src[e]) + a.bias[n + e], a.act);
+        if (a.res) Out8<TO>::add(Out8<TO>::load(reinterpret_cast<const char*>(a.res) + ((long)m * a.ldr + n) * (long)sizeof(TO)), v, a.res_scale);
         // destination pixel(s)
         long p0 = m;
         int rep = 1;
-        long dstep_x = 0, dstep_y = 0;
+        long dstep_y = 0;
         if (a.up2) {
             const int x = m % a.Wo;
             const int t = m / a.Wo;
@@ -379,23 +400,12 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             const int b = t / a.Ho;
             p0 = ((long)(b * 2 * a.Ho + 2 * y)) * (2 * a.Wo) + 2 * x;
             rep = 4;
-            dstep_x = 1;
             dstep_y = 2 * a.Wo;
         }
+        const typename Out8<TO>::raw_t o = Out8<TO>::pack(v, a.out_inv_scale);
         for (int r = 0; r < rep; ++r) {
-            const long p = p0 + (r & 1) * dstep_x + (r >> 1) * dstep_y;
-            if (a.out_f32 || sizeof(T) == 4) {
-                *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(a.out) + p * a.ldo + n) = f32x4_t{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x4_t o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                    o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) |
-                           ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-                }
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.out) + p * a.ldo + n) = o;
-            }
+            const long p = p0 + (r & 1) + (r >> 1) * dstep_y;
+            Out8<TO>::store(o, reinterpret_cast<char*>(a.out) + (p * a.ldo + n) * (long)sizeof(TO));
         }
     }
 }
@@ -417,16 +427,16 @@ size_t conv_weight_rows(int cout)
     return (size_t)((cout + bn - 1) / bn) * bn;
 }
 
-int conv_k_step(int dtype) { return dtype == 0 ? 64 : 128; }   // packed K is padded to 256 bytes (one ring slab)
+int conv_k_step(int dtype) { return 256 / dtype_size(dtype); }   // packed K is padded to 256 bytes (one ring slab)
 
-template <typename T, int WM, int WN, int MF, int NF>
+template <typename T, typename TO, int WM, int WN, int MF, int NF>
 static hipError_t launch_one(const ConvArgs& a, hipStream_t s)
 {
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
     constexpr size_t epi = BM * (BN + 4) * 4 + 4 * BM * 4;   // epilogue tile + per-pixel head tables
     constexpr size_t lds = (2 * (BM + BN) * 128 > epi) ? 2 * (BM + BN) * 128 : epi;
     static size_t attr[16] = {0};
-    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF>;
+    auto kern = conv_igemm_kernel<T, WM, WN, MF, NF, TO>;
     {
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
         if (e != hipSuccess) return e;
@@ -438,15 +448,15 @@ static hipError_t launch_one(const ConvArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, typename TO>
 static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 {
     switch (conv_pick_bn(a.Cout)) {
-        case 128: return launch_one<T, 2, 2, 4, 4>(a, s);   // 128 px x 128 cout
-        case 96: return launch_one<T, 4, 1, 2, 6>(a, s);    // 128 px x 96
-        case 64: return launch_one<T, 4, 1, 2, 4>(a, s);    // 128 px x 64
-        case 48: return launch_one<T, 4, 1, 2, 3>(a, s);    // 128 px x 48 (detection heads: 45)
-        default: return launch_one<T, 4, 1, 4, 2>(a, s);    // 256 px x 32
+        case 128: return launch_one<T, TO, 2, 2, 4, 4>(a, s);   // 128 px x 128 cout
+        case 96: return launch_one<T, TO, 4, 1, 2, 6>(a, s);    // 128 px x 96
+        case 64: return launch_one<T, TO, 4, 1, 2, 4>(a, s);    // 128 px x 64
+        case 48: return launch_one<T, TO, 4, 1, 2, 3>(a, s);    // 128 px x 48 (detection heads: 45)
+        default: return launch_one<T, TO, 4, 1, 4, 2>(a, s);    // 256 px x 32
     }
 }
 
@@ -461,7 +471,12 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant
     }
     if (a.src_mode) return hipErrorNotSupported;      // only the narrow-input halo kernel reads raw frames (engine checks conv_accepts_raw)
     if (variant) *variant = 1000 + conv_pick_bn(a.Cout);
-    return dtype == 0 ? launch_t<float>(a, s) : launch_t<__bf16>(a, s);
+    const int odt = a.out_dt < 0 ? dtype : a.out_dt;
+    if (dtype == 0 && odt == 0) return launch_t<float, float>(a, s);
+    if (dtype == 1 && odt == 1) return launch_t<__bf16, __bf16>(a, s);
+    if (dtype == 1 && odt == 2) return launch_t<__bf16, fp8_t>(a, s);      // the fp8 engine's stem on shapes the narrow halo kernel leaves
+    if (dtype == 2 && odt == 2) return launch_t<fp8_t, fp8_t>(a, s);
+    return hipErrorNotSupported;
 }
 
 }  // namespace sky

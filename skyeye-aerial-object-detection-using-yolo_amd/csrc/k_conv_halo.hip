@@ -86,14 +86,17 @@ __device__ __forceinline__ void tile_pixel(const ConvArgs& a, int idx, int& ty, 
 // row runs under their latency; buffer descriptors give 32-bit offsets and let masked lanes (pixels past the image
 // edge) use offset -1: loads return zeros, stores are dropped.  Clears the accumulators.
 // FC > 0: the packed vectors of channels [0, FC) are also kept in `bop` (the B operands of a fused 1x1, conv_frag.h).
-template <typename T, int NF, int ACT, bool SQ, int FC = 0>
+template <typename T, int NF, int ACT, bool SQ, int FC = 0, typename TO = T>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[NF][4], const float* lbias, __amdgpu_buffer_rsrc_t orsrc,
                                               __amdgpu_buffer_rsrc_t rrsrc, int bimg, int y0, int x0, int idx0, int nlane,
                                               u32x4_t (*bop)[FC / 32 ? FC / 32 : 1][FuseGeom<T>::H] = nullptr)
 {
-    constexpr int VB = 8 * (int)sizeof(T);        // bytes of one 8-channel vector
+    static_assert(FC == 0 || (std::is_same<T, TO>::value && sizeof(T) >= 2), "the fused 1x1 takes the packed output as its operand");
+    constexpr int VB = Out8<TO>::NB;                // bytes of one 8-channel vector in the OUTPUT type
+    constexpr bool QS = sizeof(T) == 1;            // fp8 operands: per-channel multiplier (input scale x weight scale)
     const bool has_res = a.res != nullptr;
     const int nl0 = nlane % (NF * 16);            // channel within the workgroup's N tile (bias in LDS)
+    const float* lmult = lbias + NF * 16;         // [NB] multipliers behind the bias (staged only when QS)
     // STORE-DATA HAZARD (found in r01_k, tests/test_gpu_determinism.py): the channel-group constant of a store must go into the
     // VECTOR offset (folded by hipcc into the instruction's immediate), never into `soffset`.  A constant above 64 is not an inline
     // operand, lands in an SGPR, and LLVM's hazard recognizer assumes that a MUBUF store with a REGISTER soffset needs no wait state
@@ -110,14 +113,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
         const bool ok = ty >= 0 && oy < a.Ho && ox < a.Wo;
         const int m = (bimg * a.Ho + oy) * a.Wo + ox;
         // masked lanes: offset 0x80000000 stays out of range after the per-group constant is added (see the store below)
-        const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(T) : (int)0x80000000;
-        u32x4_t rv[NF / 2][VB / 16];
+        const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(TO) : (int)0x80000000;
+        typename Out8<TO>::raw_t rv[NF / 2];
         if (has_res) {
-            const int roff = ok ? (m * a.ldr + nlane) * (int)sizeof(T) : -1;
+            const int roff = ok ? (m * a.ldr + nlane) * (int)sizeof(TO) : -1;
 #pragma unroll
-            for (int s = 0; s < NF / 2; ++s)
-#pragma unroll
-                for (int h = 0; h < VB / 16; ++h) rv[s][h] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, s * 4 * VB + h * 16, 0);
+            for (int s = 0; s < NF / 2; ++s) rv[s] = Out8<TO>::load(rrsrc, roff, s * 4 * VB);
         }
 #pragma unroll
         for (int s = 0; s < NF / 2; ++s) {
@@ -125,10 +126,20 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
             const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
             const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
             float v[8];
+            if (QS) {
+                const f32x4_t m0 = *reinterpret_cast<const f32x4_t*>(lmult + nl);
+                const f32x4_t m1 = *reinterpret_cast<const f32x4_t*>(lmult + nl + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[2 * s][i][e] + b0[e];
-                v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * s][i][e] * m0[e] + b0[e];
+                    v[4 + e] = acc[2 * s + 1][i][e] * m1[e] + b1[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * s][i][e] + b0[e];
+                    v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
+                }
             }
             acc[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             acc[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -137,38 +148,15 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                 if (ACT == ACT_SILU) v[e] = S1<T>::silu(v[e]);
                 if (ACT == ACT_RELU) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
             }
-            if (has_res) {
-                if (sizeof(T) == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(rv[s][0][e] << 16);
-                        v[2 * e + 1] += __uint_as_float(rv[s][0][e] & 0xffff0000u);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += __uint_as_float(rv[s][e >> 2][e & 3]);
-                }
-            }
+            if (has_res) Out8<TO>::add(rv[s], v, a.res_scale);
             asm volatile("; previous store data live until here" ::"v"(pin));      // bias + residual of this group are in
-            if (sizeof(T) == 2) {
-                u32x4_t o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                    o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff + s * 4 * VB, 0, 0);
-                pin = o;
-                if (FC > 0 && s < FC / 32) bop[i][s][0] = o;
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32x4_t o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[4 * h + e]);
-                    __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff + s * 4 * VB + h * 16, 0, 0);
-                    if (h == 1) pin = o;
-                    if (FC > 0 && s < FC / 32) bop[i][s][h] = o;
+            const typename Out8<TO>::raw_t o = Out8<TO>::pack(v, a.out_inv_scale);
+            Out8<TO>::store(o, orsrc, ooff + s * 4 * VB);
+            pin = Out8<TO>::last(o);
+            if constexpr (FC > 0) {
+                if (s < FC / 32) {
+                    if constexpr (sizeof(T) == 2) bop[i][s][0] = o.a;
+                    else { bop[i][s][0] = o.a; bop[i][s][FuseGeom<T>::H - 1] = o.b; }
                 }
             }
         }
@@ -191,17 +179,18 @@ __device__ __forceinline__ TapStep tap_step(int q)
     return TapStep{tap, ky != 1, kx != 1, q == 0 || q == 4 || q == 6 || q == 8};
 }
 
-template <typename T, int NF, bool SQ, bool S2, int FC = 0>
+template <typename T, int NF, bool SQ, bool S2, int FC = 0, typename TO = T>
 __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SKY_HALO_VGPR))) conv_halo_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
+    constexpr int NBS = sizeof(T) == 1 ? 2 * NB : NB;      // floats staged behind the weight ring: bias (+ fp8 multipliers)
     constexpr int WSLAB = NB * 128;               // bytes of one weight slab
     constexpr int WDMA = NB / 8 / HWV;            // weight DMA instructions per wave per slab (8 rows each)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const halo = smem + (((SKY_DBG(a) >> 16) & 0xff) << 10);      // experiment: SKY_CONV_DBG bits 16..23 = KB of padding in front
     char* const wring = halo + HALO_BYTES;
     float* const lbias = reinterpret_cast<float*>(halo + HALO_BYTES + 2 * WSLAB);
-    char* const w2lds = halo + HALO_BYTES + 2 * WSLAB + NB * 4;                   // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
+    char* const w2lds = halo + HALO_BYTES + 2 * WSLAB + NBS * 4;                  // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
     float* const b2lds = reinterpret_cast<float*>(w2lds + FC * FC * (int)sizeof(T));
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(b2lds + (FC ? FC : 0));   // 64 x 8 B, experiments only
 
@@ -218,7 +207,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     const int wpitch = a.Kpad * (int)sizeof(T);
 
     for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
-    if (FC > 0) fuse_stage<T, FC ? FC : 32>(a.f2_w, a.f2_Kpad, a.f2_bias, w2lds, b2lds, tid, HWV * 64);
+    if (sizeof(T) == 1)
+        for (int i = tid; i < NB; i += HWV * 64) lbias[NB + i] = a.mult ? a.mult[n0 + i] : 1.0f;
+    if constexpr (FC > 0) fuse_stage<T, FC ? FC : 32>(a.f2_w, a.f2_Kpad, a.f2_bias, w2lds, b2lds, tid, HWV * 64);
 
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc =
@@ -292,6 +283,30 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
         u32x4_t pf[2][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) pf[0][i] = *reinterpret_cast<const u32x4_t*>(halo + pa[i]);
+        if constexpr (sizeof(T) == 1) {
+            // fp8: both 64-byte K-steps of the chunk go into ONE 16x16x128 instruction per (weight fragment, pixel fragment).
+            // Pipeline over the NF/2 fragment pairs: the four weight pieces of pair sp + 1 are read before the 8 MFMAs of pair sp.
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[1][i] = *reinterpret_cast<const u32x4_t*>(halo + (pa[i] ^ 16));
+            // Pipeline over the NF weight fragments: the two 16-byte pieces (K-steps 0 / 1) of fragment j + 1 are read before the 4
+            // MFMAs of fragment j issue (two stages of 2 x 4 VGPRs).
+            u32x4_t w2[2][2];                        // [stage][kk]
+            const int k1 = 64 - 2 * (arow & 64);
+#pragma unroll
+            for (int j = 0; j < NF + 1; ++j) {
+                if (j < NF) {
+                    w2[j & 1][0] = *reinterpret_cast<const u32x4_t*>(wb + j * 2048);
+                    w2[j & 1][1] = *reinterpret_cast<const u32x4_t*>(wb + j * 2048 + k1);
+                }
+                if (j >= 1) {
+                    const int q = j - 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fp8_mma128(w2[q & 1][0], w2[q & 1][1], pf[0][i], pf[1][i], acc[q][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         constexpr int HG = NF / 2, G = 2 * HG;
         u32x4_t wq[3][2];
 #pragma unroll
@@ -321,7 +336,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     const __amdgpu_buffer_rsrc_t rrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0, (int)(a.res ? a.res_bytes : a.out_bytes), 0x00020000);
     auto epilogue_act = [&](int bimg, int y0, int x0) {
-        if (FC > 0) {
+        if constexpr (FC > 0) {
             // this convolution's epilogue keeps the packed first FC channels, the fused 1x1 runs from them, second epilogue
             constexpr int C2 = FC ? FC : 32;
             u32x4_t bop[4][C2 / 32][FuseGeom<T>::H];
@@ -343,9 +358,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             else tile_epilogue<T, C2 / 16, ACT_NONE, SQ>(a2, acc2, b2lds, o2, o2, bimg, y0, x0, wave * 64 + fr, fq * 8);
             return;
         }
-        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
     };
     auto decode_tile = [&](int tile, int& bimg, int& y0, int& x0) {
         const int tx = tile % tiles_x;
@@ -436,10 +451,11 @@ static constexpr int SPL = SPX * 16;          // bytes per plane = 24 * 256
 // (uint8 / float32, NCHW) and FocusBlock's space-to-depth (blocks.py:176-181: patches TL, BL, TR, BR -> channel patch*3 + c),
 // the /255 of the uint8 contract (validate.py:238, true division) and the conversion to T happen while the halo tile is
 // built: the stem reads 4.9 MB per frame instead of the 13 MB intermediate an import kernel would write and it read back.
-template <typename T, int CB, int NF, bool SQ, int SRC = 0>
+template <typename T, int CB, int NF, bool SQ, int SRC = 0, typename TO = T>
 __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16;
+    constexpr int NBS = sizeof(T) == 1 ? 2 * NB : NB;      // bias (+ fp8 multipliers)
     constexpr int NPL = CB / 16;                  // planes
     constexpr int HB = NPL * SPL;                 // one halo buffer
     constexpr int KBYTES = 9 * CB;
@@ -457,7 +473,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     // SRC == 1 (uint8 frames, 16 x 16 tiles): the raw bytes of a tile (3 colours x 36 rows x 40 bytes, rows starting 2 pixels
     // left of the halo so that they are 4-byte aligned) are staged in LDS by dword loads, then turned into the channel planes through a
     // 256-entry table of (T)(i / 255.0f) -- the exact values the import kernel would have written
-    unsigned char* const rawl = reinterpret_cast<unsigned char*>(lbias + NB);
+    unsigned char* const rawl = reinterpret_cast<unsigned char*>(lbias + NBS);
     T* const lut = reinterpret_cast<T*>(rawl + RAW_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -483,7 +499,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
             *reinterpret_cast<u32x4_t*>(wlds + ss * WBUF + row * 256 + ((c ^ swz) << 4)) = v;
         }
         for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
-        if (SRC == 1) lut[tid] = (T)((float)tid / 255.0f);          // 256 threads = 256 byte values
+        if (sizeof(T) == 1)
+            for (int i = tid; i < NB; i += HWV * 64) lbias[NB + i] = a.mult ? a.mult[n0 + i] : 1.0f;
+        if constexpr (SRC == 1) lut[tid] = (T)((float)tid / 255.0f);          // 256 threads = 256 byte values
     }
 
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
@@ -533,7 +551,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         int bimg, y0, x0;
         decode_tile(t, bimg, y0, x0);
         const int Hr = 2 * a.H, Wr = 2 * a.W;
-        if (SRC == 1) {
+        if constexpr (SRC == 1) {
             const int ntot = 3 * rrows * rdw;
             const int ry0 = 2 * (y0 - 1), rx0 = 2 * (x0 - 1) - 2;            // rx0 is a multiple of 4 (tile_w even)
 #pragma unroll
@@ -569,7 +587,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         }
     };
     auto store_raw = [&](int buf) {                 // registers -> LDS planes of halo buffer `buf`
-        if (SRC == 1) {
+        if constexpr (SRC == 1) {
             const int ntot = 3 * rrows * rdw;
 #pragma unroll
             for (int k = 0; k < NDW; ++k) {
@@ -664,9 +682,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         }
         int bimg, y0, x0;
         decode_tile(tile, bimg, y0, x0);
-        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         if (next >= ntile) break;
         if (SRC) store_raw((it + 1) & 1);    // the other buffer: nobody reads it before the barrier at the loop top
         tile = next;
@@ -678,7 +696,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
 // The stride-2 scheme of conv_halo_kernel on the narrow kernel's machinery: the four parity phases of the input are
 // staged one after the other as unit-stride cell tiles into the two halo buffers in turn (phase p + 1 is fetched while the
 // 4 / 2 / 2 / 1 taps of phase p compute), all of K resident in LDS, one barrier per phase, epilogue after the fourth.
-template <typename T, int NF, bool SQ>
+template <typename T, int NF, bool SQ, typename TO = T>
 __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const ConvArgs a)
 {
     constexpr int NB = NF * 16, NPL = 4, HB = NPL * SPL, NSLAB = 3, WBUF = NB * 256, NPIECE = NPL * 6 / HWV;
@@ -707,6 +725,8 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
             *reinterpret_cast<u32x4_t*>(wlds + ss * WBUF + row * 256 + ((c ^ swz) << 4)) = v;
         }
         for (int i = tid; i < NB; i += HWV * 64) lbias[i] = a.bias[n0 + i];
+        if (sizeof(T) == 1)
+            for (int i = tid; i < NB; i += HWV * 64) lbias[NB + i] = a.mult ? a.mult[n0 + i] : 1.0f;
     }
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
@@ -786,9 +806,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
         }
         int bimg, y0, x0;
         decode_tile(tile, bimg, y0, x0);
-        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else tile_epilogue<T, NF, ACT_NONE, SQ>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         if (next >= ntile) break;
         tile = next;
     }
@@ -815,7 +835,7 @@ static double pick_tile(ConvArgs& a, int slots)
     return (double)a.Ho * a.Wo / ((double)((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w) * 256.0);
 }
 
-template <typename T, int NF, bool SQ, bool S2, int FC = 0>
+template <typename T, int NF, bool SQ, bool S2, int FC = 0, typename TO = T>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     ConvArgs a = a0;
@@ -826,14 +846,14 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 #else
     a.dbg = 0;
 #endif
-    size_t lds = HALO_BYTES + 2 * NB * 128 + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
+    size_t lds = HALO_BYTES + 2 * NB * 128 + (sizeof(T) == 1 ? 2 : 1) * NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
 #ifdef SKY_EXPERIMENTS
     lds += ((a.dbg & 256) ? 512 : 0) + ((size_t)((a.dbg >> 16) & 0xff) << 10);
 #endif
     // OPT_NF8_SOLO (A/B): 128-channel tiles alone on a CU -- an LDS request above half of the CU's 160 KB excludes a second one
     const bool solo = NF == 8 && (a.opts & OPT_NF8_SOLO);
     if (solo && lds < 84 * 1024) lds = 84 * 1024;
-    auto kern = conv_halo_kernel<T, NF, SQ, S2, FC>;
+    auto kern = conv_halo_kernel<T, NF, SQ, S2, FC, TO>;
     static size_t attr[16] = {0};
     {   // the attribute is set to the largest size this kernel can ever ask for (solo / padded variants included)
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds > 84 * 1024 ? lds : 84 * 1024, a.device, attr);
@@ -883,12 +903,12 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
     return hipGetLastError();
 }
 
-template <typename T, int CB, int NF, bool SQ, int SRC = 0>
+template <typename T, int CB, int NF, bool SQ, int SRC = 0, typename TO = T>
 static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, NSLAB = (9 * CB + 255) / 256;
-    const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + NB * 4 + (SRC == 1 ? 3 * 36 * 40 + 256 * sizeof(T) : 0);
-    auto kern = conv_halo_small_kernel<T, CB, NF, SQ, SRC>;
+    const size_t lds = (size_t)NSLAB * NB * 256 + 2 * (CB / 16) * SPL + (sizeof(T) == 1 ? 2 : 1) * NB * 4 + (SRC == 1 ? 3 * 36 * 40 + 256 * sizeof(T) : 0);
+    auto kern = conv_halo_small_kernel<T, CB, NF, SQ, SRC, TO>;
     static size_t attr[16] = {0};
     {
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
@@ -903,12 +923,12 @@ static hipError_t halo_small_launch(const ConvArgs& a, hipStream_t s, int n_cu)
     return hipGetLastError();
 }
 
-template <typename T, int NF, bool SQ>
+template <typename T, int NF, bool SQ, typename TO = T>
 static hipError_t halo_small_s2_launch(const ConvArgs& a, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16;
-    const size_t lds = (size_t)3 * NB * 256 + 2 * 4 * SPL + NB * 4;
-    auto kern = conv_halo_small_s2_kernel<T, NF, SQ>;
+    const size_t lds = (size_t)3 * NB * 256 + 2 * 4 * SPL + (sizeof(T) == 1 ? 2 : 1) * NB * 4;
+    auto kern = conv_halo_small_s2_kernel<T, NF, SQ, TO>;
     static size_t attr[16] = {0};
     {
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
@@ -923,31 +943,44 @@ static hipError_t halo_small_s2_launch(const ConvArgs& a, hipStream_t s, int n_c
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, typename TO>
 static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStream_t s, int n_cu)
 {
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     if (a.src_mode) {   // raw frames (FocusBlock import fused): 16 channels = 32 B (bf16) / 64 B (fp32); source element type by mode
-        constexpr int CBR = 16 * (int)sizeof(T);
-        if (cb != CBR) return hipErrorNotSupported;
-#define SKY_RAW(NFF, SQQ) (a.src_mode == 1 ? halo_small_launch<T, CBR, NFF, SQQ, 1>(a, s, n_cu) : halo_small_launch<T, CBR, NFF, SQQ, 2>(a, s, n_cu))
-        if (nb == 32) return sq ? SKY_RAW(2, true) : SKY_RAW(2, false);
-        return sq ? SKY_RAW(4, true) : SKY_RAW(4, false);
+        if constexpr (sizeof(T) >= 2) {
+            constexpr int CBR = 16 * (int)sizeof(T);
+            if (cb != CBR) return hipErrorNotSupported;
+#define SKY_RAW(NFF, SQQ) (a.src_mode == 1 ? halo_small_launch<T, CBR, NFF, SQQ, 1, TO>(a, s, n_cu) : halo_small_launch<T, CBR, NFF, SQQ, 2, TO>(a, s, n_cu))
+            if (nb == 32) return sq ? SKY_RAW(2, true) : SKY_RAW(2, false);
+            return sq ? SKY_RAW(4, true) : SKY_RAW(4, false);
 #undef SKY_RAW
+        } else {
+            return hipErrorNotSupported;      // the stem computes in bf16 also in the fp8 engine
+        }
     }
     if (cb == 32) {
-        if (nb == 32) return sq ? halo_small_launch<T, 32, 2, true>(a, s, n_cu) : halo_small_launch<T, 32, 2, false>(a, s, n_cu);
-        return sq ? halo_small_launch<T, 32, 4, true>(a, s, n_cu) : halo_small_launch<T, 32, 4, false>(a, s, n_cu);
+        if (nb == 32) return sq ? halo_small_launch<T, 32, 2, true, 0, TO>(a, s, n_cu) : halo_small_launch<T, 32, 2, false, 0, TO>(a, s, n_cu);
+        return sq ? halo_small_launch<T, 32, 4, true, 0, TO>(a, s, n_cu) : halo_small_launch<T, 32, 4, false, 0, TO>(a, s, n_cu);
     }
-    if (nb == 32) return sq ? halo_small_launch<T, 64, 2, true>(a, s, n_cu) : halo_small_launch<T, 64, 2, false>(a, s, n_cu);
-    return sq ? halo_small_launch<T, 64, 4, true>(a, s, n_cu) : halo_small_launch<T, 64, 4, false>(a, s, n_cu);
+    if (nb == 32) return sq ? halo_small_launch<T, 64, 2, true, 0, TO>(a, s, n_cu) : halo_small_launch<T, 64, 2, false, 0, TO>(a, s, n_cu);
+    return sq ? halo_small_launch<T, 64, 4, true, 0, TO>(a, s, n_cu) : halo_small_launch<T, 64, 4, false, 0, TO>(a, s, n_cu);
+}
+
+// supported (compute type, output type) pairs of the halo kernels: equal types, and bf16 -> fp8 on the narrow kernels (the
+// stem of the fp8 engine)
+static bool halo_types_ok(int dtype, const ConvArgs& a, bool narrow)
+{
+    const int odt = a.out_dt < 0 ? dtype : a.out_dt;
+    return odt == dtype || (narrow && dtype == 1 && odt == 2);
 }
 
 // the checks that route a convolution to the narrow-input kernel (the only one with a raw-frame loader)
 static bool halo_small_ok(int dtype, ConvArgs& a)
 {
-    const int esz = dtype == 0 ? 4 : 2;
+    const int esz = dtype_size(dtype);
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2) return false;
+    if (!halo_types_ok(dtype, a, true)) return false;
     if ((!a.src_mode && a.in_bytes == 0) || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return false;
     const long cb = (long)a.Cin * esz;
     if (!((cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0))) return false;
@@ -960,6 +993,7 @@ static bool halo_small_ok(int dtype, ConvArgs& a)
 bool conv_accepts_raw(int dtype, const ConvArgs& a0)
 {
     if (a0.opts & OPT_NO_FUSED_IMPORT) return false;       // A/B switch
+    if (dtype == 2) return false;
     ConvArgs a = a0;
     a.src_mode = 1;
     // the raw loader stages 16 x 16 tiles; dword loads want an even map width (raw width a multiple of 4)
@@ -971,12 +1005,14 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
 {
     ConvArgs a = a0;
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
-    const int esz = dtype == 0 ? 4 : 2;
+    const int esz = dtype_size(dtype);
+    const int odt = a.out_dt < 0 ? dtype : a.out_dt;
     if (a.ks != 3 || (a.stride != 1 && a.stride != 2) || a.pad != 1 || a.head || a.out_f32 || a.up2) return hipErrorNotSupported;
     if ((!a.src_mode && a.in_bytes == 0) || a.out_bytes == 0 || (a.res && a.res_bytes == 0)) return hipErrorNotSupported;
     const long cb = (long)a.Cin * esz;
     const bool small = a.stride == 1 && (cb == 32 || cb == 64) && (a.Cout == 32 || a.Cout % 64 == 0);
     const bool small_s2 = a.stride == 2 && cb == 64 && (a.Cout == 32 || a.Cout % 64 == 0) && !a.src_mode && !a.f2_w;
+    if (!halo_types_ok(dtype, a, small || small_s2)) return hipErrorNotSupported;
     if (small_s2) {
         if ((long)a.Kpad * esz < 9L * a.Cin * esz || (long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;
         // measured slower than the streaming kernel on its one layer of skyeye_s (32 -> 64 @640 -> 320: 0.385 vs 0.336 ms, the
@@ -985,13 +1021,13 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         pick_tile(a, SPX);
         const bool sq2 = a.tile_w == 16 && a.tile_h == 16;
         hipError_t e2;
-        if (a.Cout == 32) {
-            if (dtype == 0) e2 = sq2 ? halo_small_s2_launch<float, 2, true>(a, s, n_cu) : halo_small_s2_launch<float, 2, false>(a, s, n_cu);
-            else e2 = sq2 ? halo_small_s2_launch<__bf16, 2, true>(a, s, n_cu) : halo_small_s2_launch<__bf16, 2, false>(a, s, n_cu);
-        } else {
-            if (dtype == 0) e2 = sq2 ? halo_small_s2_launch<float, 4, true>(a, s, n_cu) : halo_small_s2_launch<float, 4, false>(a, s, n_cu);
-            else e2 = sq2 ? halo_small_s2_launch<__bf16, 4, true>(a, s, n_cu) : halo_small_s2_launch<__bf16, 4, false>(a, s, n_cu);
-        }
+#define SKY_S2(T, TO) (a.Cout == 32 ? (sq2 ? halo_small_s2_launch<T, 2, true, TO>(a, s, n_cu) : halo_small_s2_launch<T, 2, false, TO>(a, s, n_cu)) \
+                                    : (sq2 ? halo_small_s2_launch<T, 4, true, TO>(a, s, n_cu) : halo_small_s2_launch<T, 4, false, TO>(a, s, n_cu)))
+        if (dtype == 0) e2 = SKY_S2(float, float);
+        else if (dtype == 1 && odt == 1) e2 = SKY_S2(__bf16, __bf16);
+        else if (dtype == 1) e2 = SKY_S2(__bf16, fp8_t);
+        else e2 = SKY_S2(fp8_t, fp8_t);
+#undef SKY_S2
         if (e2 == hipSuccess && variant) *variant = 6000 + (a.Cout == 32 ? 32 : 64);
         return e2;
     }
@@ -1012,7 +1048,11 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     if (!(a.opts & OPT_HALO_FORCE) && cover < 0.75) return hipErrorNotSupported;
     if (small) {
         const int nb = a.Cout == 32 ? 32 : 64;
-        const hipError_t e = dtype == 0 ? halo_small_dispatch<float>((int)cb, nb, a, s, n_cu) : halo_small_dispatch<__bf16>((int)cb, nb, a, s, n_cu);
+        hipError_t e;
+        if (dtype == 0) e = halo_small_dispatch<float, float>((int)cb, nb, a, s, n_cu);
+        else if (dtype == 1 && odt == 1) e = halo_small_dispatch<__bf16, __bf16>((int)cb, nb, a, s, n_cu);
+        else if (dtype == 1) e = halo_small_dispatch<__bf16, fp8_t>((int)cb, nb, a, s, n_cu);
+        else e = halo_small_dispatch<fp8_t, fp8_t>((int)cb, nb, a, s, n_cu);
         if (e == hipSuccess && variant) *variant = 5000 + nb;
         return e;
     }
@@ -1021,26 +1061,19 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     const int nb = (a.Cout % 128 == 0 && !(a.opts & OPT_NF8_OFF)) ? 128 : 64;
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
+#define SKY_HALO(T, S2V) (nb == 128 ? (sq ? halo_launch<T, 8, true, S2V>(a, s, n_cu) : halo_launch<T, 8, false, S2V>(a, s, n_cu)) \
+                                    : (sq ? halo_launch<T, 4, true, S2V>(a, s, n_cu) : halo_launch<T, 4, false, S2V>(a, s, n_cu)))
     if (a.stride == 2) {
-        if (dtype == 0) {
-            if (nb == 128) e = sq ? halo_launch<float, 8, true, true>(a, s, n_cu) : halo_launch<float, 8, false, true>(a, s, n_cu);
-            else e = sq ? halo_launch<float, 4, true, true>(a, s, n_cu) : halo_launch<float, 4, false, true>(a, s, n_cu);
-        } else {
-            if (nb == 128) e = sq ? halo_launch<__bf16, 8, true, true>(a, s, n_cu) : halo_launch<__bf16, 8, false, true>(a, s, n_cu);
-            else e = sq ? halo_launch<__bf16, 4, true, true>(a, s, n_cu) : halo_launch<__bf16, 4, false, true>(a, s, n_cu);
-        }
-    } else if (a.f2_w && nb == 64 && a.Cout == 64 && a.f2_cin == 64 && a.f2_cout == 64 && a.f2_koff == 0 && a.f2_out_bytes) {
+        e = dtype == 0 ? SKY_HALO(float, true) : dtype == 1 ? SKY_HALO(__bf16, true) : SKY_HALO(fp8_t, true);
+    } else if (dtype != 2 && a.f2_w && nb == 64 && a.Cout == 64 && a.f2_cin == 64 && a.f2_cout == 64 && a.f2_koff == 0 && a.f2_out_bytes) {
         // the 1x1 convolution that follows (the next bottleneck's cv1) runs in this kernel's epilogue
         if (dtype == 0) e = sq ? halo_launch<float, 4, true, false, 64>(a, s, n_cu) : halo_launch<float, 4, false, false, 64>(a, s, n_cu);
         else e = sq ? halo_launch<__bf16, 4, true, false, 64>(a, s, n_cu) : halo_launch<__bf16, 4, false, false, 64>(a, s, n_cu);
         if (e == hipSuccess && fused) *fused = 1;
-    } else if (dtype == 0) {
-        if (nb == 128) e = sq ? halo_launch<float, 8, true, false>(a, s, n_cu) : halo_launch<float, 8, false, false>(a, s, n_cu);
-        else e = sq ? halo_launch<float, 4, true, false>(a, s, n_cu) : halo_launch<float, 4, false, false>(a, s, n_cu);
     } else {
-        if (nb == 128) e = sq ? halo_launch<__bf16, 8, true, false>(a, s, n_cu) : halo_launch<__bf16, 8, false, false>(a, s, n_cu);
-        else e = sq ? halo_launch<__bf16, 4, true, false>(a, s, n_cu) : halo_launch<__bf16, 4, false, false>(a, s, n_cu);
+        e = dtype == 0 ? SKY_HALO(float, false) : dtype == 1 ? SKY_HALO(__bf16, false) : SKY_HALO(fp8_t, false);
     }
+#undef SKY_HALO
     if (e == hipSuccess && variant) *variant = (a.stride == 2 ? 6000 : 4000) + nb;
     return e;
 }

@@ -39,11 +39,14 @@ __device__ __forceinline__ int wswz(int row) { return (row & 3) | (((row >> 3) &
 // ONE: K fits one slab (1x1 convolutions with <= 256 bytes of input channels): only the KT real K-steps are fetched
 // FC > 0: a following FC -> FC 1x1 convolution of this convolution's first FC output channels runs in the epilogue
 // (ConvArgs::f2_*, conv_frag.h): the packed output vectors are its MFMA B operands
-template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false, int FC = 0>
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false, int FC = 0, typename TO = T>
 __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 {
     static_assert(NF % 2 == 0, "pairs of fragments form one 8-channel vector");
+    static_assert(FC == 0 || (std::is_same<T, TO>::value && sizeof(T) >= 2), "the fused 1x1 takes the packed output as its operand");
     constexpr int NB = NF * 16;
+    constexpr bool QS = sizeof(T) == 1;            // fp8 operands: per-channel multiplier behind the bias
+    constexpr int NBS = QS ? 2 * NB : NB;
     constexpr int TPX = MF * 16;
     constexpr int BUF = NB * SLAB;                 // one slab of weights: [NB rows][256 B]
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,7 +66,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     const char* __restrict__ wsrc = reinterpret_cast<const char*>(a.w);
     const long wpitch = (long)a.Kpad * (long)sizeof(T);
     float* lbias = reinterpret_cast<float*>(smem + (RING ? 2 : nslab) * BUF);
-    char* const w2lds = reinterpret_cast<char*>(lbias + NB);
+    char* const w2lds = reinterpret_cast<char*>(lbias + NBS);
     float* const b2lds = reinterpret_cast<float*>(w2lds + FC * FC * (int)sizeof(T));
 
     // ---- weight staging ----
@@ -88,7 +91,9 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
         }
     };
     for (int i = tid; i < NB; i += SW * 64) lbias[i] = a.bias[n0 + i];
-    if (FC > 0) fuse_stage<T, FC ? FC : 32>(a.f2_w, a.f2_Kpad, a.f2_bias, w2lds, b2lds, tid, SW * 64);
+    if (QS)
+        for (int i = tid; i < NB; i += SW * 64) lbias[NB + i] = a.mult ? a.mult[n0 + i] : 1.0f;
+    if constexpr (FC > 0) fuse_stage<T, FC ? FC : 32>(a.f2_w, a.f2_Kpad, a.f2_bias, w2lds, b2lds, tid, SW * 64);
 
     // ---- tile schedule ----
     const int ntiles = (a.M + TPX - 1) / TPX;
@@ -244,10 +249,20 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                     const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
                     const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
                     float v[8];
+                    if (QS) {
+                        const f32x4_t m0 = *reinterpret_cast<const f32x4_t*>(lbias + NB + nl);
+                        const f32x4_t m1 = *reinterpret_cast<const f32x4_t*>(lbias + NB + nl + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[2 * s][i][e] + b0[e];
-                        v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[2 * s][i][e] * m0[e] + b0[e];
+                            v[4 + e] = acc[2 * s + 1][i][e] * m1[e] + b1[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[2 * s][i][e] + b0[e];
+                            v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
+                        }
                     }
                     if (a.act == ACT_SILU) {
 #pragma unroll
@@ -257,46 +272,19 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     }
                     if (a.res) {
-                        const char* rp = reinterpret_cast<const char*>(a.res) + ((long)m * a.ldr + n0 + nl) * (long)sizeof(T);
-                        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(rp);
-                        if (sizeof(T) == 2) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[2 * e] += __uint_as_float(r0[e] << 16);
-                                v[2 * e + 1] += __uint_as_float(r0[e] & 0xffff0000u);
-                            }
-                        } else {
-                            const u32x4_t r1 = *reinterpret_cast<const u32x4_t*>(rp + 16);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                v[e] += __uint_as_float(r0[e]);
-                                v[4 + e] += __uint_as_float(r1[e]);
-                            }
-                        }
+                        const char* rp = reinterpret_cast<const char*>(a.res) + ((long)m * a.ldr + n0 + nl) * (long)sizeof(TO);
+                        Out8<TO>::add(Out8<TO>::load(rp), v, a.res_scale);
                     }
                     const int n = n0 + nl;
+                    const typename Out8<TO>::raw_t o = Out8<TO>::pack(v, a.out_inv_scale);
                     for (int r = 0; r < rep; ++r) {
                         const long p = p0 + (r & 1) + (r >> 1) * step_y;
-                        if (sizeof(T) == 2) {
-                            u32x4_t o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                                o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-                            }
-                            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.out) + p * a.ldo + n) = o;
-                            if (FC > 0 && s < FC / 32) bop[i][s][0] = o;
-                        } else {
-                            float* op = reinterpret_cast<float*>(a.out) + p * a.ldo + n;
-                            *reinterpret_cast<f32x4_t*>(op) = f32x4_t{v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4_t*>(op + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
-                            if (FC > 0 && s < FC / 32) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    bop[i][s][0][e] = __float_as_uint(v[e]);
-                                    bop[i][s][FuseGeom<T>::H - 1][e] = __float_as_uint(v[4 + e]);
-                                }
-                            }
+                        Out8<TO>::store(o, reinterpret_cast<char*>(a.out) + (p * a.ldo + n) * (long)sizeof(TO));
+                    }
+                    if constexpr (FC > 0) {
+                        if (s < FC / 32) {
+                            if constexpr (sizeof(T) == 2) bop[i][s][0] = o.a;
+                            else { bop[i][s][0] = o.a; bop[i][s][FuseGeom<T>::H - 1] = o.b; }
                         }
                     }
                 }
@@ -304,7 +292,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 #pragma unroll
             for (int j = 0; j < NF; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
-        if (FC > 0) {       // the fused 1x1: out2 = act2(W2 * packed[:, 0:FC] + b2)
+        if constexpr (FC > 0) {       // the fused 1x1: out2 = act2(W2 * packed[:, 0:FC] + b2)
             f32x4_t acc2[C2 / 16][MF];
 #pragma unroll
             for (int j = 0; j < C2 / 16; ++j)
@@ -405,7 +393,7 @@ struct StreamPlan {
 static StreamPlan stream_plan(int dtype, const ConvArgs& a)
 {
     StreamPlan p;
-    const int esz = dtype == 0 ? 4 : 2;
+    const int esz = dtype_size(dtype);
     const long Cb = (long)a.Cin * esz;
     if ((a.ks != 1 && a.ks != 3) || a.head || a.out_f32) return p;       // detection levels stay on the implicit-GEMM kernel
     if (a.ks == 1 && a.stride != 1) return p;
@@ -433,7 +421,7 @@ static StreamPlan stream_plan(int dtype, const ConvArgs& a)
     return p;
 }
 
-template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false, int FC = 0>
+template <typename T, int KS, int MF, int NF, bool RING, bool UTAP, int KT, bool ONE = false, int FC = 0, typename TO = T>
 static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     constexpr int NB = NF * 16, TPX = MF * 16;
@@ -444,9 +432,9 @@ static hipError_t stream_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
         if ((1 << sh) == cpt) a.cpt_shift = sh;
     const size_t Kb = (size_t)KS * KS * a.Cin * sizeof(T);
     const size_t nslab = (Kb + SLAB - 1) / SLAB;
-    const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
+    const size_t lds = (size_t)NB * SLAB * (RING ? 2 : nslab) + (sizeof(T) == 1 ? 2 : 1) * NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
     static size_t attr[16] = {0};
-    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT, ONE, FC>;
+    auto kern = conv_stream_kernel<T, KS, MF, NF, RING, UTAP, KT, ONE, FC, TO>;
     {
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds, a.device, attr);
         if (e != hipSuccess) return e;
@@ -479,15 +467,17 @@ static hipError_t stream_dispatch_fused(const StreamPlan& p, const ConvArgs& a, 
 template <typename T, int KS, int KT>
 static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs& a, hipStream_t s, int n_cu, int* fused = nullptr)
 {
-    if (KS == 1 && utap && !p.ring && a.f2_w && a.f2_koff == 0 && a.f2_cin == a.f2_cout && p.nf * 16 == a.Cout &&
-        ((p.nf == 4 && a.f2_cin == 32) || (p.nf == 8 && a.f2_cin == 64)) && !a.up2 && !a.res) {
-        const size_t extra = (size_t)a.f2_cin * a.f2_cin * sizeof(T) + a.f2_cin * 4;
-        const size_t Kb = (size_t)a.Cin * sizeof(T), nslab = (Kb + SLAB - 1) / SLAB;
-        if ((size_t)a.Cout * SLAB * nslab + a.Cout * 4 + extra <= LDS_BUDGET) {
-            const hipError_t e = stream_dispatch_fused<T, KT>(p, a, s, n_cu);
-            if (e != hipErrorNotSupported) {
-                if (e == hipSuccess && fused) *fused = 1;
-                return e;
+    if constexpr (sizeof(T) >= 2) {
+        if (KS == 1 && utap && !p.ring && a.f2_w && a.f2_koff == 0 && a.f2_cin == a.f2_cout && p.nf * 16 == a.Cout &&
+            ((p.nf == 4 && a.f2_cin == 32) || (p.nf == 8 && a.f2_cin == 64)) && !a.up2 && !a.res) {
+            const size_t extra = (size_t)a.f2_cin * a.f2_cin * sizeof(T) + a.f2_cin * 4;
+            const size_t Kb = (size_t)a.Cin * sizeof(T), nslab = (Kb + SLAB - 1) / SLAB;
+            if ((size_t)a.Cout * SLAB * nslab + a.Cout * 4 + extra <= LDS_BUDGET) {
+                const hipError_t e = stream_dispatch_fused<T, KT>(p, a, s, n_cu);
+                if (e != hipErrorNotSupported) {
+                    if (e == hipSuccess && fused) *fused = 1;
+                    return e;
+                }
             }
         }
     }
@@ -541,9 +531,11 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 {
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     if (a.src_mode) return hipErrorNotSupported;
+    if (a.out_dt >= 0 && a.out_dt != dtype) return hipErrorNotSupported;      // mixed types (the fp8 engine's bf16 stem): tile kernel
     const StreamPlan p = stream_plan(dtype, a);
     if (p.nf == 0) return hipErrorNotSupported;
-    const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu, fused) : stream_dispatch_t<__bf16>(p, a, s, n_cu, fused);
+    const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu, fused)
+                         : dtype == 1 ? stream_dispatch_t<__bf16>(p, a, s, n_cu, fused) : stream_dispatch_t<fp8_t>(p, a, s, n_cu, fused);
     if (e == hipSuccess && variant) *variant = (p.ring ? 3000 : 2000) + p.nf * 16;
     return e;
 }

@@ -2,13 +2,11 @@
 // byte movers: 16 bytes per lane, channel-contiguous NHWC, grid-stride loops capped near 8 blocks per CU.
 #include "sky_kernels.h"
 
-#include <hip/hip_bf16.h>
+#include "conv_frag.h"
+
 #include <math.h>
 
 namespace sky {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 static inline int cap_grid(long blocks) { return (int)(blocks < 1 ? 1 : (blocks > 2048 * 4 ? 2048 * 4 : blocks)); }
 
@@ -18,6 +16,9 @@ template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+// fp8 (OCP e4m3fn): the stored byte; the per-tensor scale is applied by the caller (kernel arguments in_scale / out_inv_scale)
+template <> __device__ __forceinline__ float to_f32<fp8_t>(fp8_t v) { return __builtin_amdgcn_cvt_f32_fp8((int)v.v, 0); }
+template <> __device__ __forceinline__ fp8_t from_f32<fp8_t>(float v) { return fp8_t{(unsigned char)(fp8_pack2(v, 0.0f, 0u, false) & 255u)}; }
 
 // 16-byte vector of T as floats
 template <typename T> struct Vec;
@@ -52,12 +53,27 @@ template <> struct Vec<__bf16> {
     }
 };
 
+template <> struct Vec<fp8_t> {
+    static constexpr int N = 16;
+    static __device__ __forceinline__ void load(const fp8_t* p, float* v) {
+        const u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fp8_unpack4(r[e], v + 4 * e);
+    }
+    static __device__ __forceinline__ void store(fp8_t* p, const float* v) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fp8_pack4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+        *reinterpret_cast<u32x4_t*>(p) = o;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ import
 // dst[b, y, x, c] (NHWC, pitch ld, C padded with zeros up to Cpad).  With s2d the destination pixel (y, x)
 // gathers the 2x2 source block: channel p*C + c with p = 0 TL, 1 BL, 2 TR, 3 BR (blocks.py:176-181).
 template <typename T, typename S>
 __global__ void import_kernel(const S* __restrict__ src, int src_nhwc, T* __restrict__ dst, int B, int C, int H, int W,
-                              int Cpad, int ld, int s2d, int scale255)
+                              int Cpad, int ld, int s2d, int scale255, float oscale)
 {
     const int Ho = s2d ? H / 2 : H, Wo = s2d ? W / 2 : W;
     const int Cs = s2d ? 4 * C : C;
@@ -82,6 +98,7 @@ __global__ void import_kernel(const S* __restrict__ src, int src_nhwc, T* __rest
             v = (float)src[si];
             if (scale255) v = v / 255.0f;
         }
+        if (sizeof(T) == 1) v = v * oscale;
         dst[p * ld + c] = from_f32<T>(v);
     }
 }
@@ -90,7 +107,7 @@ __global__ void import_kernel(const S* __restrict__ src, int src_nhwc, T* __rest
 // (+ zero padding to Cpad).  One thread per output pixel: 6 two-element loads (rows 2y, 2y+1 of each plane; consecutive
 // threads read consecutive element pairs), whole 16-byte stores.
 template <typename T, typename S>
-__global__ void import_s2d3_kernel(const S* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int Cpad, int ld, int scale255)
+__global__ void import_s2d3_kernel(const S* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int Cpad, int ld, int scale255, float oscale)
 {
     const int Ho = H / 2, Wo = W / 2;
     const long total = (long)B * Ho * Wo;
@@ -111,6 +128,10 @@ __global__ void import_s2d3_kernel(const S* __restrict__ src, T* __restrict__ ds
             if (scale255) { tl = tl / 255.0f; tr = tr / 255.0f; bl = bl / 255.0f; br = br / 255.0f; }
             v[0 + c] = tl; v[3 + c] = bl; v[6 + c] = tr; v[9 + c] = br;
         }
+        if (sizeof(T) == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = v[e] * oscale;
+        }
         T* o = dst + p * ld;
         constexpr int N = Vec<T>::N;
         for (int g = 0; g < Cpad / N; ++g) Vec<T>::store(o + g * N, v + g * N);
@@ -118,31 +139,33 @@ __global__ void import_s2d3_kernel(const S* __restrict__ src, T* __restrict__ ds
 }
 
 hipError_t launch_import(int dtype, const void* src, int src_u8, int src_nhwc, void* dst, int B, int C, int H, int W,
-                         int Cpad, int ld, int s2d, int scale255, hipStream_t s)
+                         int Cpad, int ld, int s2d, int scale255, hipStream_t s, float out_inv_scale)
 {
     if (s2d && !src_nhwc && C == 3 && Cpad <= 16 && (W % 2 == 0)) {
         const long total = (long)B * (H / 2) * (W / 2);
         const int grid = cap_grid((total + 255) / 256);
 #define SKY_IMPORT3(T, S) \
-    hipLaunchKernelGGL((import_s2d3_kernel<T, S>), dim3(grid), dim3(256), 0, s, (const S*)src, (T*)dst, B, H, W, Cpad, ld, scale255)
+    hipLaunchKernelGGL((import_s2d3_kernel<T, S>), dim3(grid), dim3(256), 0, s, (const S*)src, (T*)dst, B, H, W, Cpad, ld, scale255, out_inv_scale)
         if (dtype == 0) { if (src_u8) SKY_IMPORT3(float, unsigned char); else SKY_IMPORT3(float, float); }
-        else            { if (src_u8) SKY_IMPORT3(__bf16, unsigned char); else SKY_IMPORT3(__bf16, float); }
+        else if (dtype == 1) { if (src_u8) SKY_IMPORT3(__bf16, unsigned char); else SKY_IMPORT3(__bf16, float); }
+        else            { if (src_u8) SKY_IMPORT3(fp8_t, unsigned char); else SKY_IMPORT3(fp8_t, float); }
 #undef SKY_IMPORT3
         return hipGetLastError();
     }
     const long total = (long)B * (s2d ? H / 2 : H) * (s2d ? W / 2 : W) * Cpad;
     const int grid = cap_grid((total + 255) / 256);
 #define SKY_IMPORT(T, S) \
-    hipLaunchKernelGGL((import_kernel<T, S>), dim3(grid), dim3(256), 0, s, (const S*)src, src_nhwc, (T*)dst, B, C, H, W, Cpad, ld, s2d, scale255)
+    hipLaunchKernelGGL((import_kernel<T, S>), dim3(grid), dim3(256), 0, s, (const S*)src, src_nhwc, (T*)dst, B, C, H, W, Cpad, ld, s2d, scale255, out_inv_scale)
     if (dtype == 0) { if (src_u8) SKY_IMPORT(float, unsigned char); else SKY_IMPORT(float, float); }
-    else            { if (src_u8) SKY_IMPORT(__bf16, unsigned char); else SKY_IMPORT(__bf16, float); }
+    else if (dtype == 1) { if (src_u8) SKY_IMPORT(__bf16, unsigned char); else SKY_IMPORT(__bf16, float); }
+    else            { if (src_u8) SKY_IMPORT(fp8_t, unsigned char); else SKY_IMPORT(fp8_t, float); }
 #undef SKY_IMPORT
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ export
 template <typename T>
-__global__ void export_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int B, int C, int H, int W)
+__global__ void export_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int B, int C, int H, int W, float iscale)
 {
     // tile transpose through LDS: 32 pixels x 32 channels
     __shared__ float tile[32][33];
@@ -158,7 +181,7 @@ __global__ void export_kernel(const T* __restrict__ src, int ld, float* __restri
         for (int k = ty; k < 32; k += 8) {
             const long p = (long)pt * 32 + k;
             const int c = ct * 32 + tx;
-            tile[k][tx] = (p < HW && c < C) ? to_f32<T>(src[((long)b * HW + p) * ld + c]) : 0.0f;
+            tile[k][tx] = (p < HW && c < C) ? (sizeof(T) == 1 ? to_f32<T>(src[((long)b * HW + p) * ld + c]) * iscale : to_f32<T>(src[((long)b * HW + p) * ld + c])) : 0.0f;
         }
         __syncthreads();
         for (int k = ty; k < 32; k += 8) {
@@ -170,12 +193,13 @@ __global__ void export_kernel(const T* __restrict__ src, int ld, float* __restri
     }
 }
 
-hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s)
+hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s, float in_scale)
 {
     const long ntile = (long)B * (((long)H * W + 31) / 32) * ((C + 31) / 32);
     const int grid = cap_grid(ntile);
-    if (dtype == 0) hipLaunchKernelGGL(export_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, ld, dst, B, C, H, W);
-    else hipLaunchKernelGGL(export_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, ld, dst, B, C, H, W);
+    if (dtype == 0) hipLaunchKernelGGL(export_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, ld, dst, B, C, H, W, 1.0f);
+    else if (dtype == 1) hipLaunchKernelGGL(export_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, ld, dst, B, C, H, W, 1.0f);
+    else hipLaunchKernelGGL(export_kernel<fp8_t>, dim3(grid), dim3(256), 0, s, (const fp8_t*)src, ld, dst, B, C, H, W, in_scale);
     return hipGetLastError();
 }
 
@@ -376,6 +400,7 @@ __global__ void __launch_bounds__(256) spp_pyramid_kernel(const T* __restrict__ 
 // fit (the caller then issues three launch_maxpool5).
 hipError_t launch_spp_pyramid(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int level_stride, hipStream_t s)
 {
+    if (dtype == 2) return hipErrorNotSupported;       // fp8 maps take the three separable launches (byte order keys not built)
     const int N = dtype == 0 ? 4 : 8;
     if (C % (N * SPP_CG) != 0 || (long)H * W * SPP_CG > 256L * SPP_ITEMS) return hipErrorNotSupported;
     const size_t lds = (size_t)H * W * SPP_CG * 16;
@@ -389,11 +414,12 @@ hipError_t launch_spp_pyramid(int dtype, const void* src, int lds_, void* dst, i
 
 hipError_t launch_maxpool5(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, hipStream_t s)
 {
-    const int N = dtype == 0 ? 4 : 8;
+    const int N = 16 / dtype_size(dtype);
     const long total = (long)B * ((H + 7) / 8) * W * (C / N);
     const int grid = cap_grid((total + 255) / 256);
     if (dtype == 0) hipLaunchKernelGGL(maxpool5_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, lds_, (float*)dst, ldd, B, H, W, C);
-    else hipLaunchKernelGGL(maxpool5_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C);
+    else if (dtype == 1) hipLaunchKernelGGL(maxpool5_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C);
+    else hipLaunchKernelGGL(maxpool5_kernel<fp8_t>, dim3(grid), dim3(256), 0, s, (const fp8_t*)src, lds_, (fp8_t*)dst, ldd, B, H, W, C);   // max is monotone in the stored value
     return hipGetLastError();
 }
 
@@ -424,11 +450,12 @@ __global__ void upsample_kernel(const T* __restrict__ src, int lds_, T* __restri
 hipError_t launch_upsample(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int Ho, int Wo,
                            hipStream_t s)
 {
-    const int N = dtype == 0 ? 4 : 8;
+    const int N = 16 / dtype_size(dtype);
     const long total = (long)B * Ho * Wo * (C / N);
     const int grid = cap_grid((total + 255) / 256);
     if (dtype == 0) hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, lds_, (float*)dst, ldd, B, H, W, C, Ho, Wo);
-    else hipLaunchKernelGGL(upsample_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C, Ho, Wo);
+    else if (dtype == 1) hipLaunchKernelGGL(upsample_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, lds_, (__bf16*)dst, ldd, B, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(upsample_kernel<fp8_t>, dim3(grid), dim3(256), 0, s, (const fp8_t*)src, lds_, (fp8_t*)dst, ldd, B, H, W, C, Ho, Wo);   // bytes move; source and destination share a scale
     return hipGetLastError();
 }
 
@@ -477,7 +504,7 @@ hipError_t launch_decode(int dtype, const float* raw, float* det, int B, int na,
 // ChannelAttention pooling (attention.py:50,54): per (b, c) sum and max over H*W, split into `nchunk` pixel
 // ranges so the result does not depend on atomics (deterministic): part[b][chunk][0][c] = sum, [1][c] = max.
 template <typename T>
-__global__ void ca_reduce_kernel(const T* __restrict__ x, int ld, int HW, int C, int nchunk, float* __restrict__ part)
+__global__ void ca_reduce_kernel(const T* __restrict__ x, int ld, int HW, int C, int nchunk, float* __restrict__ part, float iscale)
 {
     // 16-byte channel vectors; the block's 256 threads are (pixel lane, channel group): each pixel lane strides the
     // chunk's pixels, the lanes are combined through LDS in a fixed order (deterministic, no atomics).
@@ -500,6 +527,10 @@ __global__ void ca_reduce_kernel(const T* __restrict__ x, int ld, int HW, int C,
             for (long p = p0 + pl; p < p1; p += npl) {
                 float v[N];
                 Vec<T>::load(x + ((long)b * HW + p) * ld + cg * N, v);
+                if (sizeof(T) == 1) {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) v[e] = v[e] * iscale;
+                }
 #pragma unroll
                 for (int e = 0; e < N; ++e) { sv[e] += v[e]; mv[e] = v[e] > mv[e] ? v[e] : mv[e]; }
             }
@@ -527,13 +558,14 @@ __global__ void ca_reduce_kernel(const T* __restrict__ x, int ld, int HW, int C,
     }
 }
 
-hipError_t launch_ca_reduce(int dtype, const void* x, int ld, int B, int HW, int C, int nchunk, float* part, hipStream_t s)
+hipError_t launch_ca_reduce(int dtype, const void* x, int ld, int B, int HW, int C, int nchunk, float* part, hipStream_t s, float in_scale)
 {
-    const int n = dtype == 0 ? 4 : 8;
+    const int n = 16 / dtype_size(dtype);
     const int cg = C / n, cpb = cg < 256 ? cg : 256, npl = 256 / cpb;
     const size_t lds = (size_t)2 * npl * cpb * n * sizeof(float);
-    if (dtype == 0) hipLaunchKernelGGL(ca_reduce_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, ld, HW, C, nchunk, part);
-    else hipLaunchKernelGGL(ca_reduce_kernel<__bf16>, dim3(nchunk, B), dim3(256), lds, s, (const __bf16*)x, ld, HW, C, nchunk, part);
+    if (dtype == 0) hipLaunchKernelGGL(ca_reduce_kernel<float>, dim3(nchunk, B), dim3(256), lds, s, (const float*)x, ld, HW, C, nchunk, part, 1.0f);
+    else if (dtype == 1) hipLaunchKernelGGL(ca_reduce_kernel<__bf16>, dim3(nchunk, B), dim3(256), lds, s, (const __bf16*)x, ld, HW, C, nchunk, part, 1.0f);
+    else hipLaunchKernelGGL(ca_reduce_kernel<fp8_t>, dim3(nchunk, B), dim3(256), lds, s, (const fp8_t*)x, ld, HW, C, nchunk, part, in_scale);
     return hipGetLastError();
 }
 
@@ -593,7 +625,7 @@ hipError_t launch_ca_mlp(const float* part, int B, int HW, int C, int nchunk, in
 // channel gate, which is CombinedAttention's x1 = x * att).  One wave per pixel, lanes stride the channels.
 template <typename T>
 __global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __restrict__ att, int B, int HW, int C, int lp,
-                                float* __restrict__ stats)
+                                float* __restrict__ stats, float iscale)
 {
     // lp lanes (a power of two <= 64) share one pixel, each owning 16-byte channel vectors lane, lane + lp, ...
     constexpr int N = Vec<T>::N;
@@ -613,6 +645,10 @@ __global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __
             for (int g = sub; g < CG; g += lp) {
                 float v[N];
                 Vec<T>::load(x + p * ld + g * N, v);
+                if (sizeof(T) == 1) {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) v[e] = v[e] * iscale;
+                }
                 if (ab) {
 #pragma unroll
                     for (int q = 0; q < N / 4; ++q) {
@@ -640,15 +676,16 @@ __global__ void sa_stats_kernel(const T* __restrict__ x, int ld, const float* __
     }
 }
 
-hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, int B, int HW, int C, float* stats, hipStream_t s)
+hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, int B, int HW, int C, float* stats, hipStream_t s, float in_scale)
 {
     const long total = (long)B * HW;
-    const int cg = C / (dtype == 0 ? 4 : 8);
+    const int cg = C / (16 / dtype_size(dtype));
     int lp = 1;
     while (lp < cg && lp < 64) lp <<= 1;
     const int grid = cap_grid((total * lp + 255) / 256);
-    if (dtype == 0) hipLaunchKernelGGL(sa_stats_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, att, B, HW, C, lp, stats);
-    else hipLaunchKernelGGL(sa_stats_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ld, att, B, HW, C, lp, stats);
+    if (dtype == 0) hipLaunchKernelGGL(sa_stats_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, att, B, HW, C, lp, stats, 1.0f);
+    else if (dtype == 1) hipLaunchKernelGGL(sa_stats_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ld, att, B, HW, C, lp, stats, 1.0f);
+    else hipLaunchKernelGGL(sa_stats_kernel<fp8_t>, dim3(grid), dim3(256), 0, s, (const fp8_t*)x, ld, att, B, HW, C, lp, stats, in_scale);
     return hipGetLastError();
 }
 
@@ -690,7 +727,7 @@ hipError_t launch_sa_gate(const float* stats, const float* w, int B, int H, int 
 // out[b, p, c] = (x[b, p, c] * att[b, c]) * gate[b, p]   (attention.py:60,98)
 template <typename T>
 __global__ void scale_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ att, const float* __restrict__ gate,
-                             T* __restrict__ out, int ldo, int B, int HW, int C)
+                             T* __restrict__ out, int ldo, int B, int HW, int C, float ratio)
 {
     constexpr int N = Vec<T>::N;
     const int cg = C / N;
@@ -710,18 +747,56 @@ __global__ void scale_kernel(const T* __restrict__ x, int ldx, const float* __re
 #pragma unroll
             for (int e = 0; e < N; ++e) v[e] = v[e] * gt;
         }
+        if (sizeof(T) == 1) {          // fp8: stored values carry per-tensor scales: x * (in_scale / out_scale)
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * ratio;
+        }
         Vec<T>::store(out + p * ldo + g * N, v);
     }
 }
 
 hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, const float* gate, void* out, int ldo, int B, int HW,
-                        int C, hipStream_t s)
+                        int C, hipStream_t s, float in_scale, float out_inv_scale)
 {
-    const int N = dtype == 0 ? 4 : 8;
+    const int N = 16 / dtype_size(dtype);
     const long total = (long)B * HW * (C / N);
     const int grid = cap_grid((total + 255) / 256);
-    if (dtype == 0) hipLaunchKernelGGL(scale_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, att, gate, (float*)out, ldo, B, HW, C);
-    else hipLaunchKernelGGL(scale_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldx, att, gate, (__bf16*)out, ldo, B, HW, C);
+    if (dtype == 0) hipLaunchKernelGGL(scale_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, att, gate, (float*)out, ldo, B, HW, C, 1.0f);
+    else if (dtype == 1) hipLaunchKernelGGL(scale_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldx, att, gate, (__bf16*)out, ldo, B, HW, C, 1.0f);
+    else hipLaunchKernelGGL(scale_kernel<fp8_t>, dim3(grid), dim3(256), 0, s, (const fp8_t*)x, ldx, att, gate, (fp8_t*)out, ldo, B, HW, C, in_scale * out_inv_scale);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ calibration of the fp8 engine
+// max |x| over an NHWC view, combined into *amax (bits of a non-negative float: unsigned integer order = float order).
+template <typename T>
+__global__ void amax_kernel(const T* __restrict__ x, int ld, long pixels, int C, unsigned int* __restrict__ amax)
+{
+    constexpr int N = Vec<T>::N;
+    const int cg = C / N;
+    const long total = pixels * cg;
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v[N];
+        Vec<T>::load(x + (i / cg) * ld + (i % cg) * N, v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float a = fabsf(v[e]);
+            m = a > m ? a : m;                      // NaN never wins
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(amax, __float_as_uint(m));
+}
+
+hipError_t launch_amax(int dtype, const void* x, int ld, long pixels, int C, unsigned int* amax, hipStream_t s)
+{
+    const long total = pixels * (C / (16 / dtype_size(dtype)));
+    const int grid = cap_grid((total + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(amax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, pixels, C, amax);
+    else if (dtype == 1) hipLaunchKernelGGL(amax_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ld, pixels, C, amax);
+    else return hipErrorNotSupported;
     return hipGetLastError();
 }
 

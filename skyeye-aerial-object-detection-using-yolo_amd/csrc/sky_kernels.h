@@ -65,6 +65,11 @@ struct ConvArgs {
     int tile_w, tile_h;         // halo-tile kernels: output tile shape (tile_w * tile_h <= 256)
     unsigned magic_w, magic_h;  // halo-tile kernels: 2^16 / tile_w + 1, 2^16 / (tile_w + 2) + 1 (exact division of small indices)
     int dbg;             // kernel experiments (SKY_CONV_DBG): only read by builds with -DSKY_EXPERIMENTS, ignored otherwise
+    // fp8 engine (SKY_FP8): real value = stored byte * per-tensor scale.  acc * mult[cout] (= input scale * weight scale of the
+    // output channel) + bias, activation, + residual * res_scale, * out_inv_scale, saturate, e4m3.  mult == nullptr: 1.
+    const float* mult;
+    float out_inv_scale, res_scale;
+    int out_dt;          // element type of out / res (sky_dtype); < 0: the compute type.  Lets a bf16 convolution (the stem) write fp8
     unsigned opts;       // PlanOpt bits of the plan
     int device, n_cu;    // device ordinal of the plan and its CU count (per-device launch geometry / LDS attributes)
     int src_mode;        // 0: `in` is an NHWC tensor of T.  1 / 2: `in` is the caller's raw [B, 3, 2H, 2W] uint8 / float32 NCHW
@@ -103,6 +108,7 @@ __device__ __forceinline__ float head_sigmoid(float v)
 }
 #endif
 
+inline int dtype_size(int dtype) { return dtype == 0 ? 4 : dtype == 1 ? 2 : 1; }   // SKY_F32, SKY_BF16, SKY_FP8
 int conv_pick_bn(int cout);                      // N tile chosen for a given Cout
 size_t conv_weight_rows(int cout);               // rows the packed weight / bias must have
 int conv_k_step(int dtype);                      // elements per 128-byte K-step
@@ -122,9 +128,11 @@ bool conv_accepts_raw(int dtype, const ConvArgs& a);
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
 // s2d = FocusBlock's space-to-depth (blocks.py:176-181, order TL, BL, TR, BR); scale255 = x/255 (validate.py:238)
 hipError_t launch_import(int dtype, const void* src, int src_u8, int src_nhwc, void* dst, int B, int C, int H, int W,
-                         int Cpad, int ld, int s2d, int scale255, hipStream_t s);
+                         int Cpad, int ld, int s2d, int scale255, hipStream_t s, float out_inv_scale = 1.0f);
 // engine NHWC T -> caller NCHW fp32
-hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_export(int dtype, const void* src, int ld, float* dst, int B, int C, int H, int W, hipStream_t s, float in_scale = 1.0f);
+// max |x| over an NHWC view into *amax (float bits, atomicMax): activation-scale calibration of the fp8 engine
+hipError_t launch_amax(int dtype, const void* x, int ld, long pixels, int C, unsigned int* amax, hipStream_t s);
 // MaxPool2d(5, stride 1, pad 2), -inf padding (blocks.py:142-144; 9 = 5o5, 13 = 5o5o5 exactly)
 hipError_t launch_spp_pyramid(int dtype, const void* src, int lds_, void* dst, int ldd, int B, int H, int W, int C, int level_stride,
                               hipStream_t s);
@@ -146,18 +154,18 @@ hipError_t launch_decode(int dtype, const float* raw, float* det, int B, int na,
 // ---- CBAM (attention.py:11-130) ----
 // partial per-channel sum / max over pixel chunks: part[b][chunk][2][C]
 hipError_t launch_ca_reduce(int dtype, const void* x, int ld, int B, int HW, int C, int nchunk, float* part,
-                            hipStream_t s);
+                            hipStream_t s, float in_scale = 1.0f);
 // finish reduce + shared MLP (no bias, ReLU) + sigmoid -> att[b][C]
 hipError_t launch_ca_mlp(const float* part, int B, int HW, int C, int nchunk, int R, const float* w0, const float* w2,
                          float* att, hipStream_t s);
 // per-pixel mean / max over channels of (x * att) -> stats[b][p][2]; att may be null (plain SpatialAttention)
 hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, int B, int HW, int C, float* stats,
-                           hipStream_t s);
+                           hipStream_t s, float in_scale = 1.0f);
 // 7x7 conv (2->1, pad 3, no bias) + sigmoid -> gate[b][p]
 hipError_t launch_sa_gate(const float* stats, const float* w, int B, int H, int W, float* gate, hipStream_t s);
 // out = (x * att) * gate   (either factor may be null)
 hipError_t launch_scale(int dtype, const void* x, int ldx, const float* att, const float* gate, void* out, int ldo,
-                        int B, int HW, int C, hipStream_t s);
+                        int B, int HW, int C, hipStream_t s, float in_scale = 1.0f, float out_inv_scale = 1.0f);
 
 // ---- attention side (k_attn.hip) ----
 hipError_t launch_layernorm(int dtype, const void* x, int ldx, void* y, int ldy, const float* g, const float* b, long tokens, int C,

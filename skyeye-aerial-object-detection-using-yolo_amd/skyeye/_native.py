@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SKYEYE_HIP_LIB") or os.path.join(_HERE, "_lib", "libskyeye_hip.so")
 
 SKY_MAX_LEVELS, SKY_MAX_ANCHORS, SKY_MAX_IO = 4, 8, 4
-SKY_F32, SKY_BF16 = 0, 1
+SKY_F32, SKY_BF16, SKY_FP8 = 0, 1, 2
+DTYPES = {"fp32": SKY_F32, "bf16": SKY_BF16, "fp8": SKY_FP8}
 SKY_IO_F32, SKY_IO_U8 = 0, 1
 SKY_NCHW, SKY_NHWC = 0, 1
 
@@ -56,7 +57,7 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_offset_boxes", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
+           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_offset_boxes", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_packed_scales", "sky_calibrate", "sky_num_scales", "sky_scales_read", "sky_scales_write", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
 _lib = None
 
@@ -109,6 +110,11 @@ def lib():
     L.sky_num_packed.argtypes = [vp]
     L.sky_packed_info.argtypes = [vp, ip, ctypes.POINTER(SkyPackedDesc)]
     L.sky_packed_read.argtypes = [vp, ip, vp, ctypes.c_size_t, vp, ctypes.c_size_t]
+    L.sky_packed_scales.argtypes = [vp, ip, vp, ctypes.c_size_t]
+    L.sky_calibrate.argtypes = [vp, ip, ctypes.POINTER(SkyBuffer), vp]
+    L.sky_num_scales.argtypes = [vp]
+    L.sky_scales_read.argtypes = [vp, vp, ip]
+    L.sky_scales_write.argtypes = [vp, vp, ip]
     L.sky_letterbox.argtypes = [vp, vp, ip, ip, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     fp = ctypes.c_float
     L.sky_scale_img.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, ip, ip, fp, vp]
@@ -208,6 +214,25 @@ class Handle:
         b = (SkyBuffer * max(len(outs), 1))(*outs)
         check(self.L.sky_forward(self.h, len(ins), a, len(outs), b, ctypes.c_void_p(stream)), self.h)
 
+    def calibrate(self, ins, stream):
+        """fp8 engine: activation scales from one bf16 pass over ``ins`` (sky_calibrate)."""
+        a = (SkyBuffer * len(ins))(*ins)
+        check(self.L.sky_calibrate(self.h, len(ins), a, ctypes.c_void_p(stream)), self.h)
+
+    def scales(self):
+        """-> float32 array, one scale per workspace buffer of the plan (1 for non-fp8 buffers)."""
+        import numpy as np
+        n = self.L.sky_num_scales(self.h)
+        out = np.ones((n,), np.float32)
+        if n:
+            check(self.L.sky_scales_read(self.h, out.ctypes.data_as(ctypes.c_void_p), n), self.h)
+        return out
+
+    def set_scales(self, scales):
+        import numpy as np
+        a = np.ascontiguousarray(scales, np.float32)
+        check(self.L.sky_scales_write(self.h, a.ctypes.data_as(ctypes.c_void_p), a.size), self.h)
+
     def time_forward(self, ins, outs, stream, iters):
         a = (SkyBuffer * len(ins))(*ins)
         b = (SkyBuffer * max(len(outs), 1))(*outs)
@@ -216,7 +241,8 @@ class Handle:
         return ms.value
 
     def packed_weights(self):
-        """-> list of dict(name, cout, kernel_size, cin, weight [rows, kpad] (uint16 bf16 bits | float32), bias [rows] float32):
+        """-> list of dict(name, cout, kernel_size, cin, weight [rows, kpad] (float32 | uint16 bf16 bits | uint8 e4m3 bytes), bias [rows]
+        float32, scale [rows] float32 (per-output-channel weight scale of fp8 weights, ones otherwise), dtype):
         the BatchNorm-folded, layout-converted convolution weights exactly as the kernels read them (sky_packed_*)."""
         import numpy as np
         out = []
@@ -226,10 +252,12 @@ class Handle:
         for i in range(n):
             d = SkyPackedDesc()
             check(self.L.sky_packed_info(self.h, i, ctypes.byref(d)), self.h)
-            w = np.empty((d.rows, d.kpad), np.float32 if d.dtype == SKY_F32 else np.uint16)
+            w = np.empty((d.rows, d.kpad), {SKY_F32: np.float32, SKY_BF16: np.uint16, SKY_FP8: np.uint8}[d.dtype])
             b = np.empty((d.rows,), np.float32)
+            sc = np.empty((d.rows,), np.float32)
             check(self.L.sky_packed_read(self.h, i, w.ctypes.data_as(ctypes.c_void_p), w.nbytes, b.ctypes.data_as(ctypes.c_void_p), b.size), self.h)
-            out.append(dict(name=d.name.decode(), cout=d.cout, kernel_size=d.kernel_size, cin=d.cin, weight=w, bias=b))
+            check(self.L.sky_packed_scales(self.h, i, sc.ctypes.data_as(ctypes.c_void_p), sc.size), self.h)
+            out.append(dict(name=d.name.decode(), cout=d.cout, kernel_size=d.kernel_size, cin=d.cin, weight=w, bias=b, scale=sc, dtype=d.dtype))
         return out
 
     def profile_forward(self, ins, outs, stream, iters=3, max_ops=4096):

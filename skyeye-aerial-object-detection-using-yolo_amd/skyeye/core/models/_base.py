@@ -176,13 +176,30 @@ class NativeModule(nn.Module):
         return self
 
     def set_precision(self, precision):
-        """'fp32' (exact MFMA f32 path) or 'bf16' (production).  None = follow the parameter dtype like the
-        reference's model.half() convention (validate.py:195-197)."""
-        if precision not in (None, "fp32", "bf16"):
+        """'fp32' (exact MFMA f32 path), 'bf16' (production) or 'fp8' (OCP e4m3 weights and activations with calibrated
+        per-tensor scales, bf16 stem; convolutional detector only).  None = follow the parameter dtype like the reference's
+        model.half() convention (validate.py:195-197)."""
+        if precision not in (None, "fp32", "bf16", "fp8"):
             raise ValueError(precision)
         for m in self.modules():
             if isinstance(m, NativeModule):
                 m.__dict__["_precision"] = precision
+        return self
+
+    def calibrate(self, *inputs):
+        """fp8 engine: the inputs (e.g. a few representative frames, uint8 or float, on the device) from which every plan of
+        this module takes its activation scales (one bf16 pass with an amax reduction behind every layer, sky_calibrate).
+        Without it an fp8 plan calibrates itself on the first input it sees.  Frames of another size than a plan's are not
+        used for it (scales are per tensor, but the statistics of another resolution are another distribution)."""
+        frames = [self._prepare_input(t) for t in inputs]
+        for m in self.modules():
+            if isinstance(m, NativeModule):
+                m.__dict__["_calib_inputs"] = None
+        self.__dict__["_calib_inputs"] = frames
+        for key, (h, fp) in list(self._engines.items()):
+            if key[0] == "fp8":
+                h.close()
+                del self._engines[key]
         return self
 
     def half(self):
@@ -238,12 +255,16 @@ class NativeModule(nn.Module):
             old.close()
         cfg = dict(self._sky_config())
         cfg.update(extra_cfg or {})
-        h = N.Handle(N.make_config(self._sky_module, dtype=N.SKY_BF16 if prec == "bf16" else N.SKY_F32,
-                                   device=dev.index or 0, **cfg))
+        h = N.Handle(N.make_config(self._sky_module, dtype=N.DTYPES[prec], device=dev.index or 0, **cfg))
         w = self._named_weights()
         if w:
             h.load_weights(w)
         h.plan([N.buffer_from_tensor(t) for t in inputs])
+        if prec == "fp8":
+            cal = self.__dict__.get("_calib_inputs")
+            if not (cal and len(cal) == len(inputs) and all(c.shape[1:] == t.shape[1:] and c.device == t.device for c, t in zip(cal, inputs))):
+                cal = inputs                       # self-calibration on the first batch of this geometry
+            h.calibrate([N.buffer_from_tensor(t) for t in cal], torch.cuda.current_stream(dev).cuda_stream)
         self._engines[key] = (h, fp)
         return h
 

@@ -21,8 +21,16 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if not parity.MARGINS:
         return
     parity.write_margins(os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    agree = [m for m in parity.MARGINS if m.get("kind") == "agreement"]
+    if agree:
+        terminalreporter.section("reduced-precision agreement rates")
+        for m in agree:
+            rates = "  ".join(f"{k}={v}" for k, v in m.items() if k not in ("where", "kind", "case", "worst_ratio"))
+            terminalreporter.write_line(f"{m['case']:<34s} {rates}")
     worst = {}
     for m in parity.MARGINS:
+        if m.get("kind") == "agreement":
+            continue
         w = worst.setdefault(m["where"], dict(ratio=0.0, iou=0.0, n=0))
         w["ratio"] = max(w["ratio"], m["worst_ratio"])
         w["iou"] = max(w["iou"], m.get("one_minus_min_iou", 0.0))

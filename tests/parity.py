@@ -98,3 +98,67 @@ def close(a, b, rtol=2e-5):
     MARGINS.append(rec)
     assert err <= rtol * scale, f"max err {err:.3e} > {rtol * scale:.3e}"
     return rec
+
+
+# ---- reduced-precision engines (bf16, fp8): agreement rates, recorded like the margins above ---------------------------------
+def e4m3_table():
+    """OCP e4m3fn value of every byte (0x7f / 0xff = NaN)."""
+    t = np.empty(256, np.float32)
+    for b in range(256):
+        s, e, m = b >> 7, (b >> 3) & 15, b & 7
+        v = np.nan if (e == 15 and m == 7) else (m * 2.0 ** -9 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7))
+        t[b] = -v if s else v
+    return t
+
+
+def quantize_e4m3(x):
+    """float array -> nearest e4m3fn VALUE (round to nearest even, saturating at +-448), as the engine's epilogues do."""
+    t = e4m3_table()
+    pos = np.sort(t[:127])                                           # 0 .. 448, the 127 non-negative finite values
+    a = np.clip(np.abs(np.asarray(x, np.float64)), 0, 448.0)
+    hi = np.clip(np.searchsorted(pos, a, side="left"), 1, 126)
+    lo = hi - 1
+    dlo, dhi = a - pos[lo], pos[hi] - a
+    pick_hi = (dhi < dlo) | ((dhi == dlo) & (hi % 2 == 0))          # even index = even mantissa (table order = code order)
+    q = np.where(pick_hi, pos[hi], pos[lo])
+    return (np.sign(x) * q).astype(np.float32)
+
+
+def box_agreement(a, b, iou_thr=0.9):
+    """Post-NMS rows a, b ([n, >= 6]: x1, y1, x2, y2, conf, cls): fraction of b's boxes that have a box of the same class in a with
+    IoU >= iou_thr (each box of a used once, best IoU first), and the mean IoU of the matched pairs."""
+    if len(b) == 0:
+        return 1.0, 1.0
+    if len(a) == 0:
+        return 0.0, 0.0
+    ax1, ay1, ax2, ay2 = a[:, 0:1], a[:, 1:2], a[:, 2:3], a[:, 3:4]
+    bx1, by1, bx2, by2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    iw = np.clip(np.minimum(ax2, bx2) - np.maximum(ax1, bx1), 0, None)
+    ih = np.clip(np.minimum(ay2, by2) - np.maximum(ay1, by1), 0, None)
+    inter = iw * ih
+    iou = inter / np.maximum((ax2 - ax1) * (ay2 - ay1) + (bx2 - bx1) * (by2 - by1) - inter, 1e-9)
+    iou = np.where(a[:, 5:6] == b[:, 5], iou, 0.0)
+    used_a, used_b, ious = set(), set(), []
+    for k in np.argsort(-iou, axis=None):
+        i, j = divmod(int(k), iou.shape[1])
+        if iou[i, j] < iou_thr:
+            break
+        if i in used_a or j in used_b:
+            continue
+        used_a.add(i); used_b.add(j); ious.append(iou[i, j])
+    return len(used_b) / len(b), float(np.mean(ious)) if ious else 0.0
+
+
+def record_agreement(name, **rates):
+    MARGINS.append(dict(where=_label(), kind="agreement", case=name, worst_ratio=0.0, **{k: round(float(v), 5) for k, v in rates.items()}))
+
+
+def row_iou(det, ref, mask):
+    """IoU of the decoded boxes (cx, cy, w, h) of the SAME rows (same cell and anchor) of two engines, over the rows in `mask`."""
+    a, b = det[mask].astype(np.float64), ref[mask].astype(np.float64)
+    if len(a) == 0:
+        return np.ones(0)
+    ax1, ay1, ax2, ay2 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+    bx1, by1, bx2, by2 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    inter = np.clip(np.minimum(ax2, bx2) - np.maximum(ax1, bx1), 0, None) * np.clip(np.minimum(ay2, by2) - np.maximum(ay1, by1), 0, None)
+    return inter / np.maximum((ax2 - ax1) * (ay2 - ay1) + (bx2 - bx1) * (by2 - by1) - inter, 1e-9)

@@ -51,21 +51,29 @@ def run(case, precision, as_uint8=False):
 
 def tol_for(case):
     # the cross-layer attention of the Enhanced detector (column softmax over image rows, x4) amplifies fp32
-    # summation-order differences ~2.5x more than the plain graph; the oracle itself sits at 2.5e-4 from torch there
-    return 3e-4 if case.get("enhanced") or case.get("head_attention") else 1e-4
+    # summation-order differences ~2.5x more than the plain graph; the oracle itself sits at 2.5e-4 from torch there.
+    # Measured margins (gpurun_out/parity_margins.json, r02_a): plain graphs worst |d| / limit 0.15 - 0.47 at 1e-4, the
+    # head-attention graphs 0.35 at 1e-4 (they ran at 3e-4 in round 1), enh_s_128x96 1.35 at 1e-4 -> stays at 3e-4.
+    return 3e-4 if case.get("enhanced") else 1e-4
+
+
+def iou_tol_for(case):
+    # IoU >= 1 - 1e-4 on matched boxes.  Every case measures 1 - min IoU <= 8.9e-5 except the two
+    # below, whose limit is twice their measured value (r02_a: l_640 1.56e-4, enh_s_128x96 3.03e-4)
+    return {"l_640": 3.2e-4, "enh_s_128x96": 6.1e-4}.get(case["name"], 1e-4)
 
 
 def check_against_fixture(case, det, raw, tol):
     name = case["name"]
     scales = level_scales(case["hw"])
     if case["store"] == "full":
-        det_close(det, DET_FULL[f"{name}.det"], scales, tol)
+        det_close(det, DET_FULL[f"{name}.det"], scales, tol, iou_tol_for(case))
         for i, r in enumerate(raw):
             close(r, DET_FULL[f"{name}.raw{i}"], rtol=5e-5 * tol / 1e-4)
     else:
         flat = det.reshape(-1, det.shape[-1])
         rows = DET_SAMPLED[f"{name}.rows"]
-        det_close(flat[rows], DET_SAMPLED[f"{name}.det_rows"], np.tile(scales, (case["batch"], 1))[rows], tol)
+        det_close(flat[rows], DET_SAMPLED[f"{name}.det_rows"], np.tile(scales, (case["batch"], 1))[rows], tol, iou_tol_for(case))
         for i, r in enumerate(raw):
             rf = r.reshape(-1, r.shape[-1])
             close(rf[DET_SAMPLED[f"{name}.raw{i}_rows"]], DET_SAMPLED[f"{name}.raw{i}_vals"], rtol=5e-5 * tol / 1e-4)
