@@ -12,6 +12,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
+// two floats -> two bf16 in one dword (low half = lo): ONE v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN).  The scalar
+// form `(__bf16)lo | (__bf16)hi << 16` costs four instructions per pair (two single conversions, a shift, an SDWA or).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi)
+{
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+
 // One OCP e4m3fn value (the fp8 of gfx950; tools/fp8_probe.hip checks the conversions and operand layouts used below).
 // real value = stored value * (per-tensor scale of the buffer it lives in); weights carry a per-output-channel scale.
 struct fp8_t { unsigned char v; };
@@ -43,8 +52,11 @@ struct S1<__bf16> {
     {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, pf), acc, 0, 0, 0);
     }
-    // bf16 output keeps 8 mantissa bits: v_exp_f32 / v_rcp_f32 (1 ulp each) are far inside that
-    static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+    // bf16 output keeps 8 mantissa bits: v_exp_f32 / v_rcp_f32 (1 ulp each) are far inside that.  The RAW exp2 instruction, not
+    // __expf: the library form wraps v_exp_f32 in a denormal-range guard (compare, two selects, a scale: 4 more VALU instructions per
+    // value), and the activation, not the MFMA, is the longer pipe of the small-K layers (45 of ~63 VALU cycles per output value of a
+    // 64-channel 3x3).  Below 2^-126 the raw result flushes to 0 -> 1 + 0, above 2^127 it is +inf -> rcp = 0 -> v * 0: both right.
+    static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 };
 template <>
 struct S1<float> {
@@ -68,7 +80,7 @@ struct S1<fp8_t> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl, pl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wh, ph, acc, 0, 0, 0);
     }
-    static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+    static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
 };
 // fp8 only: the two 16-byte fragments of a 128-byte K chunk (64-byte K-steps 0 and 1) in ONE block-scaled instruction with both
 // block scales 2^0 (E8M0 0x7f): 4x the K of the bf16 form at twice its cycles, i.e. the 5 PFLOP/s rate (MI355X_MICROARCH.md).
@@ -128,10 +140,7 @@ template <> struct Out8<__bf16> {
     {
         raw_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-            o.a[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-        }
+        for (int e = 0; e < 4; ++e) o.a[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
         return o;
     }
     static __device__ __forceinline__ void store(const raw_t& o, __amdgpu_buffer_rsrc_t r, int voff) { __builtin_amdgcn_raw_buffer_store_b128(o.a, r, voff, 0, 0); }

@@ -76,6 +76,8 @@ struct Op {
     TV in, out, res;
     // conv
     int wid = -1;          // index into Engine::convs
+    int wid1 = -1;         // fused BottleneckBlock: packed weights of cv1 (the 1x1 computed on the halo tile of the 3x3, k_conv_halo.hip CV1)
+    int c1_res = 0;        // ... with the shortcut x + cv2(cv1(x))
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 0, up2 = 0;
     int head = 0, level = 0;
     int raw_ext = -1, det_ext = -1;
@@ -152,6 +154,7 @@ struct Engine {
     void* nms_ws = nullptr;
     size_t nms_ws_bytes = 0;
     unsigned opts = 0;      // PlanOpt bits, read from the environment once per sky_plan
+    unsigned extra_opts = 0;   // PlanOpt bits forced by the engine itself (the calibration twin plans without fused bottlenecks)
     int n_cu = 256;         // compute units of cfg.device
 
     bool calibrated = false;    // fp8: activation scales are set
@@ -453,11 +456,48 @@ static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cou
     return y;
 }
 
-// BottleneckBlock (blocks.py:69-90): x + cv2(cv1(x)) iff shortcut and cin == cout
+// would the halo-tile kernel run cv2(cv1(x)) of this bottleneck as ONE launch (conv_accepts_cv1)?
+static bool bottleneck_fusable(Ctx& c, const TV& x, int cin, int hidden, int cout)
+{
+    if (!c.emit || x.dt != SKY_BF16 || cin != hidden || hidden != cout) return false;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = x.B; a.H = x.H; a.W = x.W; a.Cin = hidden; a.ldi = x.ld; a.Ho = x.H; a.Wo = x.W; a.Cout = cout; a.ldo = x.ld;
+    a.ks = 3; a.stride = 1; a.pad = 1; a.M = x.B * x.H * x.W;
+    a.Kpad = (9 * hidden + conv_k_step(SKY_BF16) - 1) / conv_k_step(SKY_BF16) * conv_k_step(SKY_BF16);
+    a.c1_Kpad = (cin + conv_k_step(SKY_BF16) - 1) / conv_k_step(SKY_BF16) * conv_k_step(SKY_BF16);
+    a.opts = c.e.opts; a.device = c.e.cfg.device; a.n_cu = c.e.n_cu; a.out_dt = SKY_BF16;
+    const double ext = ((double)a.M - 1.0) * x.ld * 2 + hidden * 2.0;
+    a.in_bytes = a.out_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;
+    return conv_accepts_cv1(SKY_BF16, a);
+}
+
+// BottleneckBlock (blocks.py:69-90): x + cv2(cv1(x)) iff shortcut and cin == cout.  fused: one launch (cv1 on the halo tile of
+// the 3x3); the output must then be another buffer than x (other tiles still read x's halo while this one writes).
 static TV bottleneck(Ctx& c, const std::string& p, const TV& x, int cin, int cout, bool shortcut, float expansion,
-                     const TV* out_into = nullptr)
+                     const TV* out_into = nullptr, bool fused = false)
 {
     const int hidden = (int)(cout * expansion);
+    if (fused) {
+        c.need(p + "cv1.conv.weight", {hidden, cin, 1, 1});
+        need_bn(c, p + "cv1.bn.", hidden);
+        c.need(p + "cv2.conv.weight", {cout, hidden, 3, 3});
+        need_bn(c, p + "cv2.bn.", cout);
+        TV y = out_into ? *out_into : c.new_tensor(x.B, x.H, x.W, cout);
+        if (y.buf == x.buf) throw Error(SKY_ERR_INVALID, p + ": a fused bottleneck cannot run in place");
+        Op op;
+        op.kind = OP_CONV;
+        op.in = x; op.out = y;
+        op.cin = hidden; op.cout = cout; op.ks = 3; op.stride = 1; op.act = ACT_SILU;
+        op.Ho = x.H; op.Wo = x.W;
+        op.cdt = x.dt;
+        op.wid1 = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}}, cin, cin, 1, op.cdt);
+        op.wid = c.pack_conv({{p + "cv2.conv.weight", p + "cv2.bn.", ""}}, hidden, hidden, 3, op.cdt);
+        op.c1_res = shortcut && cin == cout;
+        op.flops = 2.0 * x.B * x.H * x.W * ((double)hidden * cin + (double)cout * 9 * hidden);
+        c.push(op);
+        return y;
+    }
     TV u = conv_block(c, p + "cv1.", x, cin, hidden, 1, 1, true);
     ConvOpt o;
     o.out_into = out_into;
@@ -490,8 +530,22 @@ static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int 
         c.push(op);
     }
     TV y1 = Ctx::slice(cat, 0, h);
-    for (int j = 0; j < n; ++j)   // BottleneckBlock(hidden, hidden, shortcut, 1.0), blocks.py:114-117; in place on y1
-        bottleneck(c, p + "bottlenecks." + std::to_string(j) + ".", y1, h, h, shortcut, 1.0f, &y1);
+    // BottleneckBlock(hidden, hidden, shortcut, 1.0), blocks.py:114-117: in place on y1, or -- where the fused cv1 + 3x3 kernel
+    // covers the shape and there are at least two blocks -- y1 -> A -> B -> ... -> y1 through two scratch tensors
+    const bool fuse = n >= 2 && bottleneck_fusable(c, y1, h, h, h);
+    TV scratch[2];
+    if (fuse)
+        for (int k = 0; k < (n >= 3 ? 2 : 1); ++k) scratch[k] = c.new_tensor(x.B, x.H, x.W, h);
+    TV cur = y1;
+    for (int j = 0; j < n; ++j) {
+        const std::string bp = p + "bottlenecks." + std::to_string(j) + ".";
+        if (fuse) {
+            const TV dst = j == n - 1 ? y1 : scratch[j & 1];
+            cur = bottleneck(c, bp, cur, h, h, shortcut, 1.0f, &dst, true);
+        } else {
+            bottleneck(c, bp, y1, h, h, shortcut, 1.0f, &y1);
+        }
+    }
     ConvOpt o;
     o.out_into = out_into;
     return conv_block(c, p + "cv3.", cat, 2 * h, cout, 1, 1, true, o);
@@ -1282,6 +1336,10 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     const double fext = (((double)a.M - 1.0) * f.out.ld + f.cout) * dtype_size(f.out.dt);
                     a.f2_out_bytes = fext < 2147483000.0 ? (unsigned)fext : 0u;
                 }
+                if (op.wid1 >= 0) {
+                    const DevConv& d1 = e.convs[op.wid1];
+                    a.c1_w = d1.w; a.c1_bias = d1.bias; a.c1_Kpad = d1.Kpad; a.c1_res = op.c1_res;
+                }
                 int fused = 0;
                 SKY_HIP(launch_conv(op.cdt, a, s, &op.variant, &fused));
                 took_next = fused != 0;
@@ -1405,9 +1463,10 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_RING")) o |= OPT_NO_RING;
     if (env("SKY_STREAM_OLDGRID")) o |= OPT_OLDGRID;
     if (env("SKY_NO_FUSED_IMPORT")) o |= OPT_NO_FUSED_IMPORT;
-    if (env("SKY_FUSE") && !env("SKY_NO_FUSE")) o |= OPT_FUSE;
+    if (env("SKY_FUSE") && !env("SKY_NO_FUSE")) o |= OPT_FUSE | OPT_NO_FUSE_CV1;     // the older opt-in epilogue fusion: instead of the fused bottlenecks
     if (env("SKY_NO_SPP_PYRAMID")) o |= OPT_NO_SPP_PYRAMID;
     if (env("SKY_ATTN_VALU")) o |= OPT_ATTN_VALU;
+    if (env("SKY_NO_FUSE_CV1")) o |= OPT_NO_FUSE_CV1;
     if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
     return o;
 }
@@ -1429,7 +1488,7 @@ struct DeviceGuard {
 static void plan(Engine& e, const Geometry& g)
 {
     e.free_plan();
-    e.opts = read_plan_opts();
+    e.opts = read_plan_opts() | e.extra_opts;
     if (e.dtype == SKY_FP8) e.opts &= ~(unsigned)OPT_FUSE;
     {
         hipDeviceProp_t prop;
@@ -1491,6 +1550,7 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
     tw.cfg.dtype = SKY_BF16;
     tw.dtype = SKY_BF16;
     tw.weights = e.weights;
+    tw.extra_opts = OPT_NO_FUSE_CV1;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors)
     plan(tw, geometry_of(n_inputs, inputs));
     if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");
     std::vector<sky_buffer> outs(tw.out_info.size());
@@ -1750,7 +1810,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)

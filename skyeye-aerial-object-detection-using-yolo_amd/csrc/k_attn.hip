@@ -12,6 +12,8 @@
 // mask); attention_mfma_kernel is the flash-style MFMA core of the bf16 engine for plain attention over all tokens.
 #include "sky_kernels.h"
 
+#include "conv_frag.h"
+
 #include <hip/hip_bf16.h>
 #include <math.h>
 #include <stdlib.h>
@@ -255,8 +257,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const f32x4_t& src = sT[2 * ks + (e >> 1)];
-                const __bf16 lo = (__bf16)src[(e & 1) * 2], hi = (__bf16)src[(e & 1) * 2 + 1];
-                pf[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                pf[e] = pack_bf16x2(src[(e & 1) * 2], src[(e & 1) * 2 + 1]);
             }
 #pragma unroll
             for (int t = 0; t < OT; ++t) {
@@ -271,10 +272,9 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
         const float inv = 1.0f / l;
 #pragma unroll
         for (int t = 0; t < OT; ++t) {
-            const __bf16 a0 = (__bf16)(o[t][0] * inv), a1 = (__bf16)(o[t][1] * inv), a2 = (__bf16)(o[t][2] * inv), a3 = (__bf16)(o[t][3] * inv);
             uint2 w;
-            w.x = (unsigned int)__builtin_bit_cast(unsigned short, a0) | ((unsigned int)__builtin_bit_cast(unsigned short, a1) << 16);
-            w.y = (unsigned int)__builtin_bit_cast(unsigned short, a2) | ((unsigned int)__builtin_bit_cast(unsigned short, a3) << 16);
+            w.x = pack_bf16x2(o[t][0] * inv, o[t][1] * inv);
+            w.y = pack_bf16x2(o[t][2] * inv, o[t][3] * inv);
             *reinterpret_cast<uint2*>(out + qrow * ldo + h * D + t * 16 + 4 * g) = w;
         }
     }

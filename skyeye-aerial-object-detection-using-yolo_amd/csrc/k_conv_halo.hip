@@ -89,7 +89,8 @@ __device__ __forceinline__ void tile_pixel(const ConvArgs& a, int idx, int& ty, 
 template <typename T, int NF, int ACT, bool SQ, int FC = 0, typename TO = T>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[NF][4], const float* lbias, __amdgpu_buffer_rsrc_t orsrc,
                                               __amdgpu_buffer_rsrc_t rrsrc, int bimg, int y0, int x0, int idx0, int nlane,
-                                              u32x4_t (*bop)[FC / 32 ? FC / 32 : 1][FuseGeom<T>::H] = nullptr)
+                                              u32x4_t (*bop)[FC / 32 ? FC / 32 : 1][FuseGeom<T>::H] = nullptr,
+                                              const typename Out8<TO>::raw_t (*pre)[NF / 2] = nullptr)
 {
     static_assert(FC == 0 || (std::is_same<T, TO>::value && sizeof(T) >= 2), "the fused 1x1 takes the packed output as its operand");
     constexpr int VB = Out8<TO>::NB;                // bytes of one 8-channel vector in the OUTPUT type
@@ -115,7 +116,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
         // masked lanes: offset 0x80000000 stays out of range after the per-group constant is added (see the store below)
         const int ooff = ok ? (m * a.ldo + nlane) * (int)sizeof(TO) : (int)0x80000000;
         typename Out8<TO>::raw_t rv[NF / 2];
-        if (has_res) {
+        if (pre) {                       // residual vectors already in registers (fused cv1: read from the LDS tile of x)
+#pragma unroll
+            for (int s = 0; s < NF / 2; ++s) rv[s] = pre[i][s];
+        } else if (has_res) {
             const int roff = ok ? (m * a.ldr + nlane) * (int)sizeof(TO) : -1;
 #pragma unroll
             for (int s = 0; s < NF / 2; ++s) rv[s] = Out8<TO>::load(rrsrc, roff, s * 4 * VB);
@@ -148,7 +152,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                 if (ACT == ACT_SILU) v[e] = S1<T>::silu(v[e]);
                 if (ACT == ACT_RELU) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
             }
-            if (has_res) Out8<TO>::add(rv[s], v, a.res_scale);
+            if (has_res || pre) Out8<TO>::add(rv[s], v, a.res_scale);
             asm volatile("; previous store data live until here" ::"v"(pin));      // bias + residual of this group are in
             const typename Out8<TO>::raw_t o = Out8<TO>::pack(v, a.out_inv_scale);
             Out8<TO>::store(o, orsrc, ooff + s * 4 * VB);
@@ -179,9 +183,15 @@ __device__ __forceinline__ TapStep tap_step(int q)
     return TapStep{tap, ky != 1, kx != 1, q == 0 || q == 4 || q == 6 || q == 8};
 }
 
-template <typename T, int NF, bool SQ, bool S2, int FC = 0, typename TO = T>
+// CV1 (bf16, one 128-byte chunk of input channels, i.e. BottleneckBlock(64, 64)): `in` is the bottleneck's INPUT x and the 1x1
+// convolution cv1 (blocks.py:88: cv2(cv1(x))) runs on the halo tile before the taps: u = SiLU(W1 x + b1) is computed for the 18 x 18
+// halo pixels with W1 resident in LDS and written back over x IN PLACE in the same bank-conflict-free layout (zeros outside the
+// image: the 3x3's padding applies to u); the residual x of the tile's own pixels is read from the LDS tile into registers first.
+// One launch and ~2/3 of the HBM traffic of the cv1 + 3x3 pair go away.  The output must not alias x (neighbouring tiles still read it).
+template <typename T, int NF, bool SQ, bool S2, int FC = 0, typename TO = T, bool CV1 = false>
 __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SKY_HALO_VGPR))) conv_halo_kernel(const ConvArgs a)
 {
+    static_assert(!CV1 || (std::is_same<T, __bf16>::value && std::is_same<TO, __bf16>::value && !S2 && FC == 0), "fused cv1: bf16, stride 1");
     constexpr int NB = NF * 16;
     constexpr int NBS = sizeof(T) == 1 ? 2 * NB : NB;      // floats staged behind the weight ring: bias (+ fp8 multipliers)
     constexpr int WSLAB = NB * 128;               // bytes of one weight slab
@@ -189,15 +199,21 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const halo = smem + (((SKY_DBG(a) >> 16) & 0xff) << 10);      // experiment: SKY_CONV_DBG bits 16..23 = KB of padding in front
     char* const wring = halo + HALO_BYTES;
-    float* const lbias = reinterpret_cast<float*>(halo + HALO_BYTES + 2 * WSLAB);
-    char* const w2lds = halo + HALO_BYTES + 2 * WSLAB + NBS * 4;                  // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
+    constexpr int NSLABS = CV1 ? 3 : 2;                                           // ring stages (+ the resident W1 slab of the fused cv1)
+    char* const w1lds = wring + 2 * WSLAB;                                        // CV1: W1 as one weight slab [NB rows][128 B]
+    float* const lbias = reinterpret_cast<float*>(halo + HALO_BYTES + NSLABS * WSLAB);
+    char* const w2lds = halo + HALO_BYTES + NSLABS * WSLAB + NBS * 4;             // fused 1x1 (FC > 0): [FC rows][FC * sizeof(T)]
     float* const b2lds = reinterpret_cast<float*>(w2lds + FC * FC * (int)sizeof(T));
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(b2lds + (FC ? FC : 0));   // 64 x 8 B, experiments only
+    float* const b1lds = reinterpret_cast<float*>(stamps + 64);                   // CV1: b1 [NB] (behind the 512 bytes of experiment stamps)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int Cb = a.Cin * (int)sizeof(T);
     const int nchunk = Cb >> 7;
+#ifdef SKY_EXPERIMENTS
+    if ((a.dbg & 256) && tid < 64) stamps[tid] = 0ull;
+#endif
     const int n0 = blockIdx.y * NB;
     const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
     const int tiles_x = (a.Wo + tile_w - 1) / tile_w, tiles_y = (a.Ho + tile_h - 1) / tile_h;
@@ -265,6 +281,93 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fused cv1 (CV1) ----
+    typename Out8<TO>::raw_t resv[4][NF / 2];          // residual x of this lane's output vectors, taken from the LDS tile
+    if constexpr (CV1) {
+        // W1 [NB rows][128 B] goes into LDS once per workgroup, laid out like a ring slab (same row permutation and swizzle)
+        const __amdgpu_buffer_rsrc_t w1rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c1_w), 0, (int)((long)NB * a.c1_Kpad * (int)sizeof(T)), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < WDMA; ++q) {
+            const int row = (wave * WDMA + q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int j = row >> 4, r = row & 15;
+            const int ch = (j >> 1) * 32 + (r >> 2) * 8 + (j & 1) * 4 + (r & 3);
+            lds_dma16(w1rsrc, w1lds + (wave * WDMA + q) * 1024, ch * a.c1_Kpad * (int)sizeof(T) + c * 16, 0);
+        }
+        for (int i = tid; i < NB; i += HWV * 64) b1lds[i] = a.c1_bias[i];
+    }
+    auto cv1_phase = [&](int bimg, int y0, int x0, int nth_tile) {
+        if constexpr (CV1) {
+            dbg_stamp(a, stamps, nth_tile, 20);
+            if (SKY_DBG(a) & 4096) return;            // experiments: bits 512 no SiLU, 1024 no cv1 MFMAs, 2048 no write-back, 4096 no cv1 phase
+            // (1) the residual vectors of this lane's 4 x NF/2 output vectors: piece (plane fq, K-step s) of the centre pixel
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int A = (SQ ? pbi[0] + i * (18 * 32) : pbi[i]) + (hpw + 1) * 32;        // tap (1, 1)
+                const int A0 = A + (((A >> 8) & 1) << 4);
+#pragma unroll
+                for (int s = 0; s < NF / 2; ++s) resv[i][s].a = *reinterpret_cast<const u32x4_t*>(halo + (s ? A0 ^ 16 : A0));
+            }
+            __syncthreads();                       // the centre pixels of a wave's output rows lie in slots other waves rewrite below
+            dbg_stamp(a, stamps, nth_tile, 21);
+            // (2) u = SiLU(W1 x + b1) on the 22 pixel fragments of the halo tile (352 slots), 6 per wave in two passes of 3
+            const char* wb = w1lds + arow;
+            const int k1 = 64 - 2 * (arow & 64);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                // the tile's own accumulators are zero here (cleared by the epilogue): three of the four pixel columns serve as cv1's
+                auto& au = acc;
+                u32x4_t xf[3][2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int p = (wave * 6 + pass * 3 + i) * 16 + fr;                       // slots past 351 do not exist: clamp, never stored
+                    const int pc = p < HPIX ? p : HPIX - 1;
+                    const int A = fq * HPL + pc * 32 + (((pc >> 3) & 1) << 4);
+                    xf[i][0] = *reinterpret_cast<const u32x4_t*>(halo + A);
+                    xf[i][1] = *reinterpret_cast<const u32x4_t*>(halo + (A ^ 16));
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wb + j * 2048 + (kk ? k1 : 0));
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            if (!(SKY_DBG(a) & 1024)) S1<T>::mma(wf, xf[i][kk], au[j][i]);
+                    }
+                dbg_stamp(a, stamps, nth_tile, 22 + 2 * pass);
+                // (3) back into the tile, in place: this wave's pixels are read by nobody else before the barrier below
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int p = (wave * 6 + pass * 3 + i) * 16 + fr;
+                    const int hy = SQ ? (p * 3641) >> 16 : (int)(((unsigned)p * a.magic_h) >> 16), hx = p - hy * hpw;
+                    const bool inside = p < hpix && (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
+#pragma unroll
+                    for (int s = 0; s < NF / 2; ++s) {
+                        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(b1lds + s * 32 + fq * 8);
+                        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(b1lds + s * 32 + fq * 8 + 4);
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = au[2 * s][i][e] + b0[e];
+                            v[4 + e] = au[2 * s + 1][i][e] + b1[e];
+                            if (!(SKY_DBG(a) & 512)) { v[e] = S1<T>::silu(v[e]); v[4 + e] = S1<T>::silu(v[4 + e]); }
+                        }
+                        au[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        au[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        typename Out8<T>::raw_t o = Out8<T>::pack(v, 1.0f);
+                        if (!inside) o.a = u32x4_t{0u, 0u, 0u, 0u};
+                        if (p < HPIX && !(SKY_DBG(a) & 2048)) *reinterpret_cast<u32x4_t*>(halo + fq * HPL + p * 32 + ((s ^ ((p >> 3) & 1)) << 4)) = o.a;
+                    }
+                }
+            }
+            dbg_stamp(a, stamps, nth_tile, 25);
+            __syncthreads();                       // u is complete
+            dbg_stamp(a, stamps, nth_tile, 26);
+        }
+    };
 
     // One tap = 2 K-steps x NF/2 groups; group (kk, sp) = two weight fragments (8 consecutive channels per lane) x the
     // four pixel fragments of K-step kk.  Software pipeline: the weight pair of group g+2 is read from LDS before the 8
@@ -358,9 +461,10 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             else tile_epilogue<T, C2 / 16, ACT_NONE, SQ>(a2, acc2, b2lds, o2, o2, bimg, y0, x0, wave * 64 + fr, fq * 8);
             return;
         }
-        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
+        const typename Out8<TO>::raw_t (*pre)[NF / 2] = CV1 && a.c1_res ? resv : nullptr;
+        if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, nullptr, pre);
+        else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, nullptr, pre);
+        else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, nullptr, pre);
     };
     auto decode_tile = [&](int tile, int& bimg, int& y0, int& x0) {
         const int tx = tile % tiles_x;
@@ -378,6 +482,11 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     int bimg, y0, x0;
     decode_tile(tile, bimg, y0, x0);
     const int G = nchunk * 9;
+#ifdef SKY_EXPERIMENTS
+    // experiment: phase offset between the two workgroups that share a CU (second half of the grid): bits 24..30 of SKY_CONV_DBG x 1024 cycles
+    if ((int)blockIdx.x >= (int)gridDim.x / 2)
+        for (int k = ((a.dbg >> 24) & 0xff); k > 0; --k) __builtin_amdgcn_s_sleep(16);
+#endif
     const TapStep first = tap_step<S2>(0);
     __syncthreads();                                   // bias staged
     const TapStep second = tap_step<S2>(1);
@@ -395,6 +504,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             }
             wait_vmcnt0();                              // this wave's DMA (slab g, the halo) has landed (and its older stores)
             __syncthreads();                           // ... and everybody else's; compute(g - 1) is over everywhere
+            if (CV1 && g == 0) cv1_phase(bimg, y0, x0, nth);
             int nq = q + 1, nchk = chunk;
             if (nq == 9) { nq = 0; ++nchk; }
             dbg_stamp(a, stamps, nth, 1 + 2 * g);
@@ -625,8 +735,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
                 if (sizeof(T) == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const __bf16 lo = (__bf16)rawv[SRC == 2 ? k : 0][SRC == 2 ? (2 * e) % EPC : 0], hi = (__bf16)rawv[SRC == 2 ? k : 0][SRC == 2 ? (2 * e + 1) % EPC : 0];
-                        o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                        o[e] = pack_bf16x2(rawv[SRC == 2 ? k : 0][SRC == 2 ? (2 * e) % EPC : 0], rawv[SRC == 2 ? k : 0][SRC == 2 ? (2 * e + 1) % EPC : 0]);
                     }
                 } else {
 #pragma unroll
@@ -835,7 +944,7 @@ static double pick_tile(ConvArgs& a, int slots)
     return (double)a.Ho * a.Wo / ((double)((a.Ho + a.tile_h - 1) / a.tile_h) * ((a.Wo + a.tile_w - 1) / a.tile_w) * 256.0);
 }
 
-template <typename T, int NF, bool SQ, bool S2, int FC = 0, typename TO = T>
+template <typename T, int NF, bool SQ, bool S2, int FC = 0, typename TO = T, bool CV1 = false>
 static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 {
     ConvArgs a = a0;
@@ -846,14 +955,14 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
 #else
     a.dbg = 0;
 #endif
-    size_t lds = HALO_BYTES + 2 * NB * 128 + (sizeof(T) == 1 ? 2 : 1) * NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0);
+    size_t lds = HALO_BYTES + (CV1 ? 3 : 2) * NB * 128 + (sizeof(T) == 1 ? 2 : 1) * NB * 4 + (FC ? FC * FC * sizeof(T) + FC * 4 : 0) + (CV1 ? 512 + NB * 4 : 0);
 #ifdef SKY_EXPERIMENTS
     lds += ((a.dbg & 256) ? 512 : 0) + ((size_t)((a.dbg >> 16) & 0xff) << 10);
 #endif
     // OPT_NF8_SOLO (A/B): 128-channel tiles alone on a CU -- an LDS request above half of the CU's 160 KB excludes a second one
     const bool solo = NF == 8 && (a.opts & OPT_NF8_SOLO);
     if (solo && lds < 84 * 1024) lds = 84 * 1024;
-    auto kern = conv_halo_kernel<T, NF, SQ, S2, FC, TO>;
+    auto kern = conv_halo_kernel<T, NF, SQ, S2, FC, TO, CV1>;
     static size_t attr[16] = {0};
     {   // the attribute is set to the largest size this kernel can ever ask for (solo / padded variants included)
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(kern), lds > 84 * 1024 ? lds : 84 * 1024, a.device, attr);
@@ -1000,10 +1109,36 @@ bool conv_accepts_raw(int dtype, const ConvArgs& a0)
     return a.Cin == 16 && !a.res && halo_small_ok(dtype, a) && a.tile_w == 16 && a.tile_h == 16 && a.W % 2 == 0;
 }
 
+// the fused cv1 + 3x3 form (conv_halo_kernel CV1): bf16, 64 -> 64 -> 64 channels (one 128-byte chunk, one 64-channel N tile)
+static bool cv1_shape_ok(int dtype, ConvArgs& a)
+{
+    if (dtype != 1 || (a.out_dt >= 0 && a.out_dt != 1)) return false;
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2 || a.src_mode || a.f2_w) return false;
+    if (a.Cin != 64 || a.Cout != 64 || a.c1_Kpad < 64) return false;
+    if (a.in_bytes == 0 || a.out_bytes == 0) return false;
+    if ((long)a.Kpad * 2 < 9L * 128 || (a.opts & (OPT_HALO_OFF | OPT_NO_FUSE_CV1))) return false;
+    const double cover = pick_tile(a, HPIX);
+    return (a.opts & OPT_HALO_FORCE) || cover >= 0.75;
+}
+
+bool conv_accepts_cv1(int dtype, const ConvArgs& a0)
+{
+    ConvArgs a = a0;
+    return cv1_shape_ok(dtype, a);
+}
+
 // returns hipErrorNotSupported when the shape is not covered / not worth it (caller falls back to the streaming kernel)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* variant, int* fused)
 {
     ConvArgs a = a0;
+    if (a.c1_w) {       // planned as a fused bottleneck: there is no other kernel for this op
+        if (!cv1_shape_ok(dtype, a)) return hipErrorInvalidValue;
+        const int n_cu1 = a.n_cu > 0 ? a.n_cu : 256;
+        const bool sq1 = a.tile_w == 16 && a.tile_h == 16;
+        const hipError_t e1 = sq1 ? halo_launch<__bf16, 4, true, false, 0, __bf16, true>(a, s, n_cu1) : halo_launch<__bf16, 4, false, false, 0, __bf16, true>(a, s, n_cu1);
+        if (e1 == hipSuccess && variant) *variant = 7064;
+        return e1;
+    }
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const int esz = dtype_size(dtype);
     const int odt = a.out_dt < 0 ? dtype : a.out_dt;

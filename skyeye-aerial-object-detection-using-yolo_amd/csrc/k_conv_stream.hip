@@ -323,8 +323,7 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                             u32x4_t o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-                                o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+                                o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
                             }
                             *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(a.f2_out) + (long)m * a.f2_ldo + nl) = o;
                         } else {

@@ -46,8 +46,7 @@ template <> struct Vec<__bf16> {
         u32x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-            o[e] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+            o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
         }
         *reinterpret_cast<u32x4_t*>(p) = o;
     }

@@ -29,6 +29,7 @@ enum PlanOpt : unsigned {
     OPT_FUSE = 1u << 9,              // SKY_FUSE=1           1x1 convolutions in the producer's epilogue (measured neutral)
     OPT_NO_SPP_PYRAMID = 1u << 10,   // SKY_NO_SPP_PYRAMID
     OPT_ATTN_VALU = 1u << 11,        // SKY_ATTN_VALU        exact attention core for bf16 too
+    OPT_NO_FUSE_CV1 = 1u << 12,      // SKY_NO_FUSE_CV1      bottleneck cv1 as its own launch (default: fused into the 3x3 where covered)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -83,6 +84,11 @@ struct ConvArgs {
     void* f2_out;
     int f2_cin, f2_cout, f2_ldo, f2_act, f2_Kpad, f2_koff;
     unsigned f2_out_bytes;
+    // fused cv1 of a BottleneckBlock (halo-tile kernel, CV1): `in` is the bottleneck's input x, u = SiLU(c1_w x + c1_bias) is computed
+    // on the halo tile in LDS and the 3x3 runs on u; c1_res: add x (the shortcut, blocks.py:88-90), taken from the LDS tile
+    const void* c1_w;    // T [Cin rows][c1_Kpad], BatchNorm folded, null = not fused
+    const float* c1_bias;
+    int c1_Kpad, c1_res;
     unsigned out_bytes, res_bytes;   // extents of the output / residual views in bytes (0 = 2 GiB or more)
     unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)
     // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
@@ -123,6 +129,9 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr, int* fused = nullptr);
 // would launch_conv run this (3x3, stride 1, 16-channel) convolution on the kernel that reads raw frames (ConvArgs::src_mode)?
 bool conv_accepts_raw(int dtype, const ConvArgs& a);
+// would launch_conv run this 3x3 convolution with the preceding 1x1 (ConvArgs::c1_*) fused on the halo tile?  (plan-time query:
+// the engine then emits one launch for the cv1 + cv2 pair of a BottleneckBlock and gives it an output that does not alias x)
+bool conv_accepts_cv1(int dtype, const ConvArgs& a);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
