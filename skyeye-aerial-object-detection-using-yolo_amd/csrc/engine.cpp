@@ -1261,7 +1261,8 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         t.opts = e.opts; t.device = cf.device; t.n_cu = e.n_cu;
                         t.out_dt = nx.out.dt;
                         const double oext = (((double)t.M - 1.0) * nx.out.ld + nx.cout) * dtype_size(nx.out.dt);
-                        t.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
+                        // 2 GiB or more: the convolution is launched over batch slices (below), each within the 32-bit range
+                        t.out_bytes = oext < 2147483000.0 ? (unsigned)oext : (unsigned)(((double)nx.Ho * nx.Wo - 1.0) * nx.out.ld * dtype_size(nx.out.dt) + 1);
                         if (conv_accepts_raw(nx.cdt, t)) {
                             raw_src = src.data;
                             raw_mode = src.dtype == SKY_IO_U8 ? 1 : 2;
@@ -1341,7 +1342,46 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     a.c1_w = d1.w; a.c1_bias = d1.bias; a.c1_Kpad = d1.Kpad; a.c1_res = op.c1_res;
                 }
                 int fused = 0;
-                SKY_HIP(launch_conv(op.cdt, a, s, &op.variant, &fused));
+                // The kernels address a view with 32-bit byte offsets (buffer descriptors): a view of 2 GiB or more (skyeye_l's
+                // 64-channel 768 x 768 maps at B = 32) is run as several launches over batch slices, each below the limit.
+                const bool raw_in = a.src_mode != 0;
+                const double in_img = raw_in ? 3.0 * (2.0 * a.H) * (2.0 * a.W) * (a.src_mode == 1 ? 1 : 4)
+                                             : (double)a.H * a.W * a.ldi * dtype_size(op.cdt);
+                const double out_img = op.head ? 0.0 : (double)a.Ho * a.Wo * (op.up2 ? 4.0 : 1.0) * a.ldo * dtype_size(op.out.dt);
+                const double res_img = a.res ? (double)a.Ho * a.Wo * a.ldr * dtype_size(op.out.dt) : 0.0;
+                const double worst = std::max(in_img, std::max(out_img, res_img));
+                int bs = a.B;
+                if (worst * a.B >= 2147483000.0 && !a.f2_w) bs = std::max(1, (int)(2147483000.0 / worst));
+                if (bs >= a.B) {
+                    SKY_HIP(launch_conv(op.cdt, a, s, &op.variant, &fused));
+                } else {
+                    const int Bfull = a.B;
+                    const ConvArgs a0 = a;
+                    for (int b0 = 0; b0 < Bfull; b0 += bs) {
+                        const int nb = std::min(bs, Bfull - b0);
+                        a = a0;
+                        a.B = nb;
+                        a.M = nb * a.Ho * a.Wo;
+                        a.in = (const char*)a0.in + (size_t)(in_img * b0);
+                        const double iext = raw_in ? in_img * nb : ((double)nb * a.H * a.W - 1.0) * a.ldi * dtype_size(op.cdt) + (double)op.cin * dtype_size(op.cdt);
+                        a.in_bytes = iext < 2147483000.0 ? (unsigned)iext : 0u;
+                        if (op.head) {
+                            if (a0.raw) a.raw = a0.raw + (size_t)b0 * a.na * a.Ho * a.Wo * a.no;
+                            a.det = a0.det + (size_t)b0 * a.det_rows * a.no;
+                        } else {
+                            const int oes = dtype_size(op.out.dt);
+                            a.out = (char*)a0.out + (size_t)(out_img * b0);
+                            const double oext = (((double)a.M * (op.up2 ? 4.0 : 1.0) - 1.0) * a.ldo + op.cout) * oes;
+                            a.out_bytes = oext < 2147483000.0 ? (unsigned)oext : 0u;
+                            if (a0.res) {
+                                a.res = (const char*)a0.res + (size_t)(res_img * b0);
+                                const double rext = (((double)a.M - 1.0) * a.ldr + op.cout) * oes;
+                                a.res_bytes = rext < 2147483000.0 ? (unsigned)rext : 0u;
+                            }
+                        }
+                        SKY_HIP(launch_conv(op.cdt, a, s, &op.variant, &fused));
+                    }
+                }
                 took_next = fused != 0;
                 break;
             }

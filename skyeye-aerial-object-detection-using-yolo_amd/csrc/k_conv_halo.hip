@@ -484,8 +484,13 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     const int G = nchunk * 9;
 #ifdef SKY_EXPERIMENTS
     // experiment: phase offset between the two workgroups that share a CU (second half of the grid): bits 24..30 of SKY_CONV_DBG x 1024 cycles
-    if ((int)blockIdx.x >= (int)gridDim.x / 2)
-        for (int k = ((a.dbg >> 24) & 0xff); k > 0; --k) __builtin_amdgcn_s_sleep(16);
+    {
+        // which workgroups are delayed: the second half of the grid, or (bit 30) the ones whose waves sit in an odd wave slot of their SIMD
+        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));      // HW_REG_HW_ID, wave_id
+        const bool late = (a.dbg & (1 << 30)) ? (slot & 1u) != 0 : (int)blockIdx.x >= (int)gridDim.x / 2;
+        if (late)
+            for (int k = ((a.dbg >> 24) & 0x3f); k > 0; --k) __builtin_amdgcn_s_sleep(16);
+    }
 #endif
     const TapStep first = tap_step<S2>(0);
     __syncthreads();                                   // bias staged
@@ -776,8 +781,31 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         const int next = tile + gridDim.x;
         if (next < ntile) issue_halo(next, (it + 1) & 1);      // SRC: the raw loads fly under the MFMAs; converted below
         const char* hb = hlds + (it & 1) * HB;
+        if constexpr (sizeof(T) == 1) {
+            // fp8: K-steps in pairs through the 16x16x128 instruction; an odd last K-step through the 16x16x32 pair
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
+            for (int kp = 0; kp < NKS / 2; ++kp) {
+                u32x4_t pf[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        pf[h][i] = *reinterpret_cast<const u32x4_t*>(hb + (SQ ? pbi[0] + i * (18 * 16) : pbi[i]) + toff[2 * kp + h]);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    u32x4_t wf[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ks = 2 * kp + h;
+                        wf[h] = *reinterpret_cast<const u32x4_t*>(wfrag + (ks >> 2) * WBUF + ((j >> 1) * 32 + (j & 1) * 4) * 256 + ((((ks & 3) * 4 + fq) ^ wsw0) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fp8_mma128(wf[0], wf[1], pf[0][i], pf[1][i], acc[j][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = (sizeof(T) == 1 ? NKS / 2 * 2 : 0); ks < NKS; ++ks) {
             u32x4_t pf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const u32x4_t*>(hb + (SQ ? pbi[0] + i * (18 * 16) : pbi[i]) + toff[ks]);

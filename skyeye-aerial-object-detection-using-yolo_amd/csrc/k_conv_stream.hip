@@ -194,6 +194,28 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     auto compute_n = [&](const u32x4_t (&cur)[MF][4], int wb, auto nkk_tag) {
         constexpr int NKK = decltype(nkk_tag)::value;
         const char* base = smem + wb + wrow0 * SLAB;
+        if constexpr (sizeof(T) == 1 && NKK % 2 == 0) {
+            // fp8: two 64-byte K-steps per 16x16x128 instruction (fp8_mma128): half the MFMA count at the same K.  Pipeline over
+            // (K-step pair kp, weight fragment j): the two pieces of fragment j + 1 are read before the MF MFMAs of fragment j.
+            constexpr int G8 = (NKK / 2) * NF;
+            u32x4_t w2[2][2];
+#pragma unroll
+            for (int g = 0; g < G8 + 1; ++g) {
+                if (g < G8) {
+                    const int kp = g / NF, j = g % NF;
+                    const char* wp = base + ((j >> 1) * 32 + (j & 1) * 4) * SLAB;
+                    w2[g & 1][0] = *reinterpret_cast<const u32x4_t*>(wp + ((((2 * kp) * 4 + fq) ^ wsw0) << 4));
+                    w2[g & 1][1] = *reinterpret_cast<const u32x4_t*>(wp + ((((2 * kp + 1) * 4 + fq) ^ wsw0) << 4));
+                }
+                if (g >= 1) {
+                    const int q = g - 1, kp = q / NF, j = q % NF;
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) fp8_mma128(w2[q & 1][0], w2[q & 1][1], cur[i][2 * kp], cur[i][2 * kp + 1], acc[j][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         constexpr int G = NKK * (NF / 2);
         u32x4_t wq[3][2];
 #pragma unroll
@@ -482,6 +504,17 @@ static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs
     }
     if (!utap) {   // narrow inputs (the stem): per-lane tap, only built for the 32-channel tile
         if (KS == 3 && !p.ring && p.nf == 2) return stream_launch<T, 3, 4, 2, false, false, KT>(a, s, n_cu);
+        if constexpr (sizeof(T) == 1 && KS == 1 && KT == 1) {
+            // 1x1 over 32 fp8 channels (32 bytes per pixel: half a K-step; the other half is masked per lane): the fp8 engine's
+            // stage-1 bottleneck cv1, which would otherwise fall to the tile kernel
+            if (!p.ring && (size_t)a.Cin * sizeof(T) <= 64) {
+                switch (p.nf) {
+                    case 8: return stream_launch<T, 1, 2, 8, false, false, 1, true>(a, s, n_cu);
+                    case 4: return stream_launch<T, 1, 2, 4, false, false, 1, true>(a, s, n_cu);
+                    default: return stream_launch<T, 1, 4, 2, false, false, 1, true>(a, s, n_cu);
+                }
+            }
+        }
         return hipErrorNotSupported;
     }
     if (p.ring) return KT == 4 ? stream_launch<T, KS, 2, 8, true, true, 4>(a, s, n_cu) : hipErrorNotSupported;
