@@ -98,6 +98,7 @@ DETECTOR_CASES = [
     dict(name="s_1280", model="skyeye_s", batch=1, hw=(1280, 1280), seed=107, store="sampled"),
     dict(name="l_640", model="skyeye_l", batch=1, hw=(640, 640), seed=108, store="sampled"),
     dict(name="enh_s_128x96", model="skyeye_s", batch=2, hw=(128, 96), seed=109, store="full", enhanced=True),
+    dict(name="l_1280", model="skyeye_l", batch=1, hw=(1280, 1280), seed=113, store="sampled"),     # config 4's per-GPU graph at its own size
 ]
 N_SAMPLED_ROWS = 4096
 
@@ -106,6 +107,7 @@ N_SAMPLED_ROWS = 4096
 HA_CASES = [
     dict(name="ha_s_128x128", model="skyeye_s", batch=2, hw=(128, 128), seed=111, store="full", head_attention=True),
     dict(name="ha_s_128x256", model="skyeye_s", batch=1, hw=(128, 256), seed=112, store="full", head_attention=True),
+    dict(name="ha_s_1280", model="skyeye_s", batch=1, hw=(1280, 1280), seed=114, store="sampled", head_attention=True),   # config 3 at its own size
 ]
 
 # ---- NMS wrapper cases -----------------------------------

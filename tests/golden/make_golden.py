@@ -297,6 +297,24 @@ def gen_head_attention():
         h, w = case["hw"]
         x = torch.from_numpy(seeded_scene(case["batch"], h, w, case["seed"])).float() / 255.0
         det, raw = m(x)
+        if case["store"] == "sampled":           # full size: SHA-256 of the tensor + sampled rows, like detectors_sampled.npz
+            name = case["name"]
+            detn = det.numpy().astype(np.float32)
+            flat = detn.reshape(-1, detn.shape[-1])
+            rows = np.random.default_rng(case["seed"]).choice(flat.shape[0], N_SAMPLED_ROWS, replace=False)
+            rows.sort()
+            full[f"{name}.rows"] = rows.astype(np.int64)
+            full[f"{name}.det_rows"] = flat[rows]
+            full[f"{name}.sha256"] = np.frombuffer(hashlib.sha256(detn.tobytes()).digest(), dtype=np.uint8)
+            full[f"{name}.absmean"] = np.asarray(np.abs(flat.astype(np.float64)).mean(axis=0), dtype=np.float64)
+            for i, r in enumerate(raw):
+                rf = r.numpy().astype(np.float32).reshape(-1, r.shape[-1])
+                rr = np.random.default_rng(case["seed"] + 1 + i).choice(rf.shape[0], min(512, rf.shape[0]), replace=False)
+                rr.sort()
+                full[f"{name}.raw{i}_rows"] = rr.astype(np.int64)
+                full[f"{name}.raw{i}_vals"] = rf[rr]
+            print(f"  head-attention {name} det {tuple(det.shape)} (sampled)")
+            continue
         full[f"{case['name']}.det"] = det.numpy().astype(np.float32)
         for i, r in enumerate(raw):
             full[f"{case['name']}.raw{i}"] = r.numpy().astype(np.float32)

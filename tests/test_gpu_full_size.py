@@ -59,3 +59,61 @@ def test_other_variants_are_deterministic_and_batch_independent(variant, batch, 
     assert torch.equal(a, b), f"{variant}: two runs of the same batch differ in {int((a != b).sum())} values"
     one, _ = m(x[batch - 1:])
     assert torch.equal(one[0], a[batch - 1]), f"{variant}: last frame of the batch differs from the frame run alone"
+
+
+@pytest.mark.parametrize("variant", ["skyeye_l", "skyeye_s_ha"])
+def test_configs_3_and_4_at_their_own_size_b32_1280(variant):
+    """BASELINE.json configs[2] (attention heads on) and configs[3]'s per-GPU shard (skyeye_l), bf16, 32 frames of 1280 x 1280:
+    two runs bit-identical, frames of the batch equal the frames run alone, outputs finite and in range."""
+    from helpers import variant_enhanced
+    m = build_detector(variant_cfg(variant), variant_enhanced(variant))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params(variant).items()}, strict=True)
+    m.eval().set_precision("bf16")
+    x = torch.from_numpy(seeded_scene(32, 1280, 1280, 81)).cuda()
+    a, _ = m(x, return_raw=False)
+    b, _ = m(x, return_raw=False)
+    assert a.shape == (32, 100800, 15)
+    assert bool(torch.isfinite(a).all())
+    assert torch.equal(a, b), f"{variant}: two runs of the same batch differ in {int((a != b).sum())} values"
+    for i in (0, 17, 31):
+        one, _ = m(x[i:i + 1], return_raw=False)
+        assert torch.equal(one[0], a[i]), f"{variant}: frame {i} of the batch differs from the frame run alone"
+    assert float(a[..., 4:].min()) >= 0.0 and float(a[..., 4:].max()) <= 1.0
+
+
+def test_bf16_vs_fp32_engine_post_nms_at_b32_1280():
+    """A whole-graph bf16 check with teeth at the benchmarked configuration: post-NMS, IoU-matched box agreement of the bf16
+    engine with the fp32 engine on the same 32 frames (thresholds from the measured values, printed by conftest)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import calibrate_objectness
+    from parity import box_agreement, record_agreement
+    from skyeye.utils.metrics import non_max_suppression
+    x = torch.from_numpy(seeded_scene(32, 1280, 1280, 83)).cuda()
+    P = detector_params("skyeye_s")
+    kept = {}
+    shift = None
+    for prec in ("fp32", "bf16"):
+        m = build_detector(variant_cfg("skyeye_s"))
+        m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in P.items()}, strict=True)
+        m.eval().set_precision(prec)
+        if shift is None:
+            shift = calibrate_objectness(m, x[:4], 0.002, 0.25)
+        else:
+            with torch.no_grad():
+                for layer in m.detection_head.detection_layers:
+                    layer.bias.view(-1, 15)[:, 4] += shift
+            m.refresh_weights()
+        outs = []
+        for i in range(0, 32, 8):                       # the fp32 engine's arena at B = 32 is large: 8 frames at a time
+            det, _ = m(x[i:i + 8], return_raw=False)
+            outs += [o.cpu().numpy() for o in non_max_suppression(det, 0.25, 0.45, mode="corrected")]
+        kept[prec] = outs
+    r50 = [box_agreement(a, b, 0.5) for a, b in zip(kept["bf16"], kept["fp32"])]
+    r90 = [box_agreement(a, b, 0.9) for a, b in zip(kept["bf16"], kept["fp32"])]
+    n_ref = sum(len(b) for b in kept["fp32"])
+    m50, m90, miou = float(np.mean([r[0] for r in r50])), float(np.mean([r[0] for r in r90])), float(np.mean([r[1] for r in r50]))
+    record_agreement("skyeye_s B=32 @1280 bf16 vs fp32 engine (post-NMS)", boxes_ref=n_ref, matched_iou50=m50, matched_iou90=m90, mean_iou=miou)
+    assert n_ref > 500
+    assert m50 > 0.85 and miou > 0.9, (m50, m90, miou)

@@ -84,7 +84,10 @@ def oracle_detector(case):
     return O.detector_forward(P, x, cfg["nc"], enhanced=case.get("enhanced", False), head_attention=case.get("head_attention", False))
 
 
-@pytest.mark.parametrize("case", HA_CASES, ids=[c["name"] for c in HA_CASES])
+_HA_SMALL = [c for c in HA_CASES if c["store"] == "full"]     # the 1280 x 1280 case is for the GPU engine (minutes on the CPU oracle)
+
+
+@pytest.mark.parametrize("case", _HA_SMALL, ids=[c["name"] for c in _HA_SMALL])
 def test_head_attention_detector_matches_reference_composition(case):
     """D5 wiring: the reference's own WindowedSelfAttention / TransformerLayer modules composed ahead of
     the detection convolutions (tests/golden/make_golden.py: ComposedDetector(head_attention=True))."""
