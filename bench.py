@@ -114,7 +114,8 @@ def calibrate_objectness(model, x, target=0.01, conf=0.25):
 FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded by launch_conv)
     ("halo3x3", "conv_halo_kernel: 3x3 halo tile + weight ring (stride 1 and 2)", lambda v: 4000 <= v < 5000 or 6000 <= v < 7000),
     ("halo_narrow", "conv_halo_small_kernel: stem / narrow-input 3x3, K resident", lambda v: 5000 <= v < 6000),
-    ("halo_cv1", "conv_halo_cv1_kernel: bottleneck 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
+    ("halo_cv1", "conv_halo_kernel<CV1>: bottleneck 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
+    ("stem_down", "stem_down_kernel: frames -> FocusBlock 3x3 -> 3x3 stride 2 in one kernel", lambda v: 8000 <= v < 9000),
     ("stream_resident", "conv_stream_kernel: 1x1 (and narrow 3x3), weights resident in LDS", lambda v: 2000 <= v < 3000),
     ("stream_ring", "conv_stream_kernel: large-K 1x1, weight ring", lambda v: 3000 <= v < 4000),
     ("tile", "conv_igemm_kernel: detection levels (N = 45) + fallback shapes", lambda v: 1000 <= v < 2000),
@@ -264,11 +265,17 @@ def main():
         stream = torch.cuda.current_stream(dev).cuda_stream
         prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], stream, iters=3)
         fam = {}
+        last = "non_conv"
         for i, (ms, fl, tag) in enumerate(prof):
-            e = fam.setdefault(family_of(tag), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, variants=set()))
-            e["launches"] += 1; e["ms"] += ms; e["flops"] += fl; e["bytes"] += h.op_bytes(i)
-            if tag // 10000 == 2:
-                e["variants"].add(tag % 10000)
+            folded = tag // 10000 == 2 and tag % 10000 >= 9000       # an op another launch computed: its FLOPs belong to that launch
+            name = last if folded else family_of(tag)
+            e = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, variants=set()))
+            e["ms"] += ms; e["flops"] += fl
+            if not folded:
+                e["launches"] += 1; e["bytes"] += h.op_bytes(i)
+                if tag // 10000 == 2:
+                    e["variants"].add(tag % 10000)
+                last = name
         peak = PEAK_TFLOPS[a.precision]
         pmc, pmc_src = {}, None
         if a.model == "skyeye_s" and B == 32 and S == 1280 and a.precision == "bf16":

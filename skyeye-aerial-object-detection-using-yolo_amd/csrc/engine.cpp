@@ -78,6 +78,7 @@ struct Op {
     int wid = -1;          // index into Engine::convs
     int wid1 = -1;         // fused BottleneckBlock: packed weights of cv1 (the 1x1 computed on the halo tile of the 3x3, k_conv_halo.hip CV1)
     int c1_res = 0;        // ... with the shortcut x + cv2(cv1(x))
+    int stem_down = 0;     // this FocusBlock convolution and the stride-2 convolution behind it can run as ONE kernel (k_stem_down.hip)
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 0, up2 = 0;
     int head = 0, level = 0;
     int raw_ext = -1, det_ext = -1;
@@ -874,6 +875,18 @@ static BackboneOut backbone(Ctx& c, const std::string& p, int ext, int B, int C,
     const int c4 = scaled_channels(base * 8, wm), c5 = scaled_channels(base * 16, wm);
     TV s = focus(c, p + "stage1.0.", ext, B, C, H, W, c1, 3);                                   // backbone.py:48
     s = conv_block(c, p + "stage1.1.", s, c1, c2, 3, 2, true);                                  // :50
+    if (c.emit && c.e.dtype == SKY_BF16 && C == 3 && c1 == 32 && c2 == 64 && !(c.e.opts & OPT_NO_STEM_DOWN) && c.e.ops.size() >= 3) {
+        // import (space-to-depth) -> stem 3x3 -> 3x3 stride 2: with uint8 frames the three ops collapse into k_stem_down.hip at run time
+        Op& down = c.e.ops[c.e.ops.size() - 1];
+        Op& stem = c.e.ops[c.e.ops.size() - 2];
+        const Op& imp = c.e.ops[c.e.ops.size() - 3];
+        if (imp.kind == OP_IMPORT && imp.s2d && stem.kind == OP_CONV && down.kind == OP_CONV && stem.in.buf == imp.out.buf &&
+            down.in.buf == stem.out.buf && down.in.off == stem.out.off && !stem.res.valid() && !down.res.valid() && !stem.fuse_next &&
+            !down.fuse_next && !down.fused_prev) {
+            stem.stem_down = 1;
+            down.fused_prev = 1;
+        }
+    }
     s = csp(c, p + "stage1.2.", s, c2, c2, scaled_depth(3, dm), true, 0.5f);                    // :52
     s = conv_block(c, p + "stage2.0.", s, c2, c3, 3, 2, true);                                  // :58
     TV p3 = csp(c, p + "stage2.1.", s, c3, c3, scaled_depth(9, dm), true, 0.5f, p3_into);       // :60
@@ -1235,6 +1248,9 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     bool took_next = false;     // the previous op's kernel also computed this (fused_prev) op
     const void* raw_src = nullptr;   // set by a skipped FocusBlock import: the next convolution reads the caller's frames
     int raw_mode = 0;
+    bool stem_down_now = false;      // set by a skipped import: the stem op launches the fused stem + stride-2 kernel
+    StemDownArgs stem_down_args;
+    memset(&stem_down_args, 0, sizeof(stem_down_args));
     for (size_t oi = 0; oi < e.ops.size(); ++oi) {
         Op& op = e.ops[oi];
         if (op.fused_prev && took_next) {
@@ -1250,6 +1266,27 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 const sky_buffer& src = ins[op.in.ext];
                 // FocusBlock: when the convolution that follows runs on the kernel that reads the raw frames itself
                 // (space-to-depth, /255 and conversion in its halo loader) the import is skipped
+                if (op.s2d && op.src_c == 3 && src.layout != SKY_NHWC && !op.force_nhwc && src.dtype == SKY_IO_U8 && oi + 2 < e.ops.size() &&
+                    e.ops[oi + 1].stem_down) {
+                    // uint8 frames: import + stem + stride-2 convolution in one kernel (the stem op below launches it)
+                    const Op& st = e.ops[oi + 1];
+                    const Op& dn = e.ops[oi + 2];
+                    StemDownArgs sa;
+                    memset(&sa, 0, sizeof(sa));
+                    sa.frames = (const unsigned char*)src.data;
+                    sa.B = st.in.B; sa.Hr = op.src_h; sa.Wr = op.src_w;
+                    sa.w1 = e.convs[st.wid].w; sa.bias1 = e.convs[st.wid].bias; sa.kpad1 = e.convs[st.wid].Kpad;
+                    sa.w2 = e.convs[dn.wid].w; sa.bias2 = e.convs[dn.wid].bias; sa.kpad2 = e.convs[dn.wid].Kpad;
+                    sa.out = tv_ptr(e, dn.out, ins, n_in, outs, n_out);
+                    sa.Ho = dn.Ho; sa.Wo = dn.Wo; sa.ldo = dn.out.ld; sa.c1 = st.cout; sa.c2 = dn.cout;
+                    sa.opts = e.opts; sa.device = cf.device; sa.n_cu = e.n_cu;
+                    if (stem_down_supported(sa)) {
+                        stem_down_args = sa;
+                        stem_down_now = true;
+                        op.variant = 9100;
+                        break;
+                    }
+                }
                 if (op.s2d && op.src_c == 3 && src.layout != SKY_NHWC && !op.force_nhwc && oi + 1 < e.ops.size()) {
                     Op& nx = e.ops[oi + 1];
                     if (nx.kind == OP_CONV && nx.in.buf == op.out.buf && nx.in.off == op.out.off && nx.ks == 3 && nx.stride == 1 && !nx.res.valid()) {
@@ -1280,6 +1317,13 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                                       op.in.B, op.in.C, op.in.H, op.in.W, s, tv_scale(e, op.in)));
                 break;
             case OP_CONV: {
+                if (stem_down_now) {
+                    stem_down_now = false;
+                    SKY_HIP(launch_stem_down(stem_down_args, s));
+                    op.variant = 8064;
+                    took_next = true;                  // the stride-2 convolution behind this op is done too
+                    break;
+                }
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
                 const DevConv& d = e.convs[op.wid];
@@ -1507,6 +1551,7 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_SPP_PYRAMID")) o |= OPT_NO_SPP_PYRAMID;
     if (env("SKY_ATTN_VALU")) o |= OPT_ATTN_VALU;
     if (env("SKY_NO_FUSE_CV1")) o |= OPT_NO_FUSE_CV1;
+    if (env("SKY_NO_STEM_DOWN")) o |= OPT_NO_STEM_DOWN;
     if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
     return o;
 }
@@ -1590,7 +1635,7 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
     tw.cfg.dtype = SKY_BF16;
     tw.dtype = SKY_BF16;
     tw.weights = e.weights;
-    tw.extra_opts = OPT_NO_FUSE_CV1;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors)
+    tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
     plan(tw, geometry_of(n_inputs, inputs));
     if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");
     std::vector<sky_buffer> outs(tw.out_info.size());
@@ -1850,7 +1895,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)

@@ -30,6 +30,7 @@ enum PlanOpt : unsigned {
     OPT_NO_SPP_PYRAMID = 1u << 10,   // SKY_NO_SPP_PYRAMID
     OPT_ATTN_VALU = 1u << 11,        // SKY_ATTN_VALU        exact attention core for bf16 too
     OPT_NO_FUSE_CV1 = 1u << 12,      // SKY_NO_FUSE_CV1      bottleneck cv1 as its own launch (default: fused into the 3x3 where covered)
+    OPT_NO_STEM_DOWN = 1u << 13,     // SKY_NO_STEM_DOWN     stem and first stride-2 convolution as two launches (default: one kernel where covered)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -132,6 +133,25 @@ bool conv_accepts_raw(int dtype, const ConvArgs& a);
 // would launch_conv run this 3x3 convolution with the preceding 1x1 (ConvArgs::c1_*) fused on the halo tile?  (plan-time query:
 // the engine then emits one launch for the cv1 + cv2 pair of a BottleneckBlock and gives it an output that does not alias x)
 bool conv_accepts_cv1(int dtype, const ConvArgs& a);
+
+// ---- stem + first stride-2 convolution in one kernel (k_stem_down.hip; bf16, uint8 NCHW frames, 3 -> 32 -> 64 channels) ----
+struct StemDownArgs {
+    const unsigned char* frames;   // [B, 3, Hr, Wr] uint8
+    int B, Hr, Wr;                 // raw frame size; the stem map is Hr/2 x Wr/2
+    const void* w1;                // stem weights, bf16 [32 rows][kpad1], K = (tap, 16 stored channels of which 12 are real), BN folded
+    const float* bias1;
+    int kpad1;
+    const void* w2;                // stride-2 convolution, bf16 [64 rows][kpad2], K = (tap, 32)
+    const float* bias2;
+    int kpad2;
+    void* out;                     // bf16 NHWC view [B, Ho, Wo, 64] with pixel stride ldo
+    int Ho, Wo, ldo;
+    int c1, c2;
+    unsigned opts;
+    int device, n_cu;
+};
+bool stem_down_supported(const StemDownArgs& a);
+hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
