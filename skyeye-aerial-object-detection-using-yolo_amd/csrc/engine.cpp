@@ -156,6 +156,10 @@ struct Engine {
     size_t nms_ws_bytes = 0;
     unsigned opts = 0;      // PlanOpt bits, read from the environment once per sky_plan
     unsigned extra_opts = 0;   // PlanOpt bits forced by the engine itself (the calibration twin plans without fused bottlenecks)
+    // Sub-batch section: ops [0, sec_end) -- the high-resolution head of the detector graph, whose per-layer tensors of a whole
+    // batch (0.2 - 0.8 GB at B = 32) are far beyond the 256 MiB Infinity Cache -- run slice by slice of `sec_sub` frames, all section
+    // ops for one slice before the next slice, so that a layer's output is still cache-resident when the next layer reads it.
+    int sec_end = 0, sec_sub = 0;
     int n_cu = 256;         // compute units of cfg.device
 
     bool calibrated = false;    // fp8: activation scales are set
@@ -1251,14 +1255,15 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     bool stem_down_now = false;      // set by a skipped import: the stem op launches the fused stem + stride-2 kernel
     StemDownArgs stem_down_args;
     memset(&stem_down_args, 0, sizeof(stem_down_args));
-    for (size_t oi = 0; oi < e.ops.size(); ++oi) {
+    int sl_b0 = 0, sl_nb = -1;       // batch slice the ops run on (sl_nb < 0: the whole batch)
+    auto exec_op = [&](size_t oi) {
         Op& op = e.ops[oi];
         if (op.fused_prev && took_next) {
             took_next = false;
             op.variant = 9000;
             ++op_index;
             if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
-            continue;
+            return;
         }
         took_next = false;
         switch (op.kind) {
@@ -1275,9 +1280,13 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     memset(&sa, 0, sizeof(sa));
                     sa.frames = (const unsigned char*)src.data;
                     sa.B = st.in.B; sa.Hr = op.src_h; sa.Wr = op.src_w;
+                    if (sl_nb >= 0) {
+                        sa.frames += (size_t)sl_b0 * 3 * op.src_h * op.src_w;
+                        sa.B = sl_nb;
+                    }
                     sa.w1 = e.convs[st.wid].w; sa.bias1 = e.convs[st.wid].bias; sa.kpad1 = e.convs[st.wid].Kpad;
                     sa.w2 = e.convs[dn.wid].w; sa.bias2 = e.convs[dn.wid].bias; sa.kpad2 = e.convs[dn.wid].Kpad;
-                    sa.out = tv_ptr(e, dn.out, ins, n_in, outs, n_out);
+                    sa.out = (char*)tv_ptr(e, dn.out, ins, n_in, outs, n_out) + (sl_nb >= 0 ? (size_t)sl_b0 * dn.Ho * dn.Wo * dn.out.ld * 2 : 0);
                     sa.Ho = dn.Ho; sa.Wo = dn.Wo; sa.ldo = dn.out.ld; sa.c1 = st.cout; sa.c2 = dn.cout;
                     sa.opts = e.opts; sa.device = cf.device; sa.n_cu = e.n_cu;
                     if (stem_down_supported(sa)) {
@@ -1301,15 +1310,21 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         // 2 GiB or more: the convolution is launched over batch slices (below), each within the 32-bit range
                         t.out_bytes = oext < 2147483000.0 ? (unsigned)oext : (unsigned)(((double)nx.Ho * nx.Wo - 1.0) * nx.out.ld * dtype_size(nx.out.dt) + 1);
                         if (conv_accepts_raw(nx.cdt, t)) {
-                            raw_src = src.data;
+                            raw_src = src.data;      // (the convolution's own slicing below offsets it)
                             raw_mode = src.dtype == SKY_IO_U8 ? 1 : 2;
                             op.variant = 9100;
                             break;
                         }
                     }
                 }
-                SKY_HIP(launch_import(op.out.dt, src.data, src.dtype == SKY_IO_U8, op.force_nhwc || src.layout == SKY_NHWC, tv_ptr(e, op.out, ins, n_in, outs, n_out),
-                                      op.out.B, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld, op.s2d, src.dtype == SKY_IO_U8, s, 1.0f / tv_scale(e, op.out)));
+                {
+                    const size_t sbytes = (size_t)op.src_c * op.src_h * op.src_w * (src.dtype == SKY_IO_U8 ? 1 : 4);
+                    const size_t dbytes = (size_t)op.out.H * op.out.W * op.out.ld * dtype_size(op.out.dt);
+                    const int b0 = sl_nb >= 0 ? sl_b0 : 0, nb = sl_nb >= 0 ? sl_nb : op.out.B;
+                    SKY_HIP(launch_import(op.out.dt, (const char*)src.data + b0 * sbytes, src.dtype == SKY_IO_U8, op.force_nhwc || src.layout == SKY_NHWC,
+                                          (char*)tv_ptr(e, op.out, ins, n_in, outs, n_out) + b0 * dbytes, nb, op.src_c, op.src_h, op.src_w, op.out.C, op.out.ld,
+                                          op.s2d, src.dtype == SKY_IO_U8, s, 1.0f / tv_scale(e, op.out)));
+                }
                 break;
             }
             case OP_EXPORT:
@@ -1396,13 +1411,14 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 const double worst = std::max(in_img, std::max(out_img, res_img));
                 int bs = a.B;
                 if (worst * a.B >= 2147483000.0 && !a.f2_w) bs = std::max(1, (int)(2147483000.0 / worst));
-                if (bs >= a.B) {
+                const int first = sl_nb >= 0 ? sl_b0 : 0, last = sl_nb >= 0 ? sl_b0 + sl_nb : a.B;      // the batch range of this call
+                if (sl_nb >= 0 && a.f2_w) throw Error(SKY_ERR_STATE, "sub-batch section with an epilogue-fused pair");
+                if (bs >= a.B && sl_nb < 0) {
                     SKY_HIP(launch_conv(op.cdt, a, s, &op.variant, &fused));
                 } else {
-                    const int Bfull = a.B;
                     const ConvArgs a0 = a;
-                    for (int b0 = 0; b0 < Bfull; b0 += bs) {
-                        const int nb = std::min(bs, Bfull - b0);
+                    for (int b0 = first; b0 < last; b0 += bs) {
+                        const int nb = std::min(bs, last - b0);
                         a = a0;
                         a.B = nb;
                         a.M = nb * a.Ho * a.Wo;
@@ -1495,7 +1511,20 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                                 amax + op.out.buf, s));
         ++op_index;
         if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
+    };
+    size_t oi = 0;
+    if (e.sec_end > 0 && !marks && !amax) {       // (per-op profiling and calibration passes run the plain order)
+        const int B = e.ops[0].out.B;
+        for (int b0 = 0; b0 < B; b0 += e.sec_sub) {
+            sl_b0 = b0;
+            sl_nb = std::min(e.sec_sub, B - b0);
+            for (size_t k = 0; k < (size_t)e.sec_end; ++k) exec_op(k);
+        }
+        sl_b0 = 0;
+        sl_nb = -1;
+        oi = (size_t)e.sec_end;
     }
+    for (; oi < e.ops.size(); ++oi) exec_op(oi);
 }
 
 static void collect_spec(Engine& e)
@@ -1570,6 +1599,36 @@ struct DeviceGuard {
     }
 };
 
+// The sub-batch section of a detector plan (Engine::sec_end): the leading run of convolutions on maps of at least 1/8 of the frame
+// side.  Opt-in, SKY_SUBBATCH=<frames>: MEASURED SLOWER on MI355X (skyeye_s bf16 B = 32 @1280: 5 780 frames/s whole-batch order,
+// 5 724 / 5 514 / 5 201 with slices of 16 / 8 / 4 frames) -- the producer's stores do not stay in the Infinity Cache for the consumer,
+// and the slices quarter the parallelism of every launch.  Kept as a switch for the record (experiments/README.md).  Buffers the
+// section touches are made to coexist: slice k + 1 of an early layer runs after slice k of a later one.
+static void plan_section(Engine& e)
+{
+    e.sec_end = e.sec_sub = 0;
+    const char* v = getenv("SKY_SUBBATCH");
+    const int sub = v ? atoi(v) : 0;
+    if (sub <= 0 || e.ops.size() < 4 || (e.cfg.module != SKY_MOD_DETECTOR && e.cfg.module != SKY_MOD_ENHANCED_DETECTOR)) return;
+    if (e.ops[0].kind != OP_IMPORT || e.ops[0].out.B < 2 * sub) return;
+    const int Hmin = e.ops[1].in.H / 4;
+    size_t k = 1;
+    for (; k < e.ops.size(); ++k) {
+        const Op& op = e.ops[k];
+        const bool folded = op.fused_prev && e.ops[k - 1].stem_down;          // the stride-2 convolution the stem kernel computes
+        if (op.kind != OP_CONV || op.head || op.fuse_next || (op.fused_prev && !folded) || op.in.H < Hmin || op.in.B != e.ops[0].out.B) break;
+    }
+    if (k < 4) return;
+    e.sec_end = (int)k;
+    e.sec_sub = sub;
+    for (size_t i = 0; i < k; ++i)
+        for (int b : {e.ops[i].in.buf, e.ops[i].out.buf, e.ops[i].res.buf})
+            if (b >= 0) {
+                e.bufs[b].first = 0;
+                e.bufs[b].last = std::max(e.bufs[b].last, (int)k - 1);
+            }
+}
+
 static void plan(Engine& e, const Geometry& g)
 {
     e.free_plan();
@@ -1585,6 +1644,7 @@ static void plan(Engine& e, const Geometry& g)
     e.spec.clear();
     Ctx c(e, true);
     build(c, g);
+    plan_section(e);
     place_buffers(e);
     SKY_HIP(hipMalloc(&e.arena, e.arena_bytes));
     SKY_HIP(hipMalloc(&e.zero_page, 256));

@@ -17,24 +17,27 @@ out = {}
 for k, v in agg.items():
     if not v["launches"]:
         continue
-    m = re.search(r"conv_stream_kernelI(DF16b|f)Li(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)E", k)
+    m = re.search(r"conv_stream_kernelI(DF16b|f|NS_5fp8_tE)Li(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)E", k)
     name = k.split("(")[0][:100]
     variant = None
-    m2 = re.search(r"conv_stream_kernel<.*?(\d), (\d), (true|false), (true|false), (\d)(?:, (?:true|false), \d+)?>", k)
+    m2 = re.search(r"conv_stream_kernel<[^,]+, \d, (\d), (\d), (true|false), (true|false)", k)      # <T, KS, MF, NF, RING, UTAP, ...>
     if m:
         variant = (3000 if m.group(5) == "1" else 2000) + int(m.group(4)) * 16
     elif m2:
         variant = (3000 if m2.group(3) == "true" else 2000) + int(m2.group(2)) * 16
     elif "conv_halo_small_kernel" in k:
-        mh = re.search(r"conv_halo_small_kernelI(?:DF16b|f)Li(\d+)ELi(\d)E", k) or re.search(r"conv_halo_small_kernel<.*?(\d+), (\d),", k)
+        mh = re.search(r"conv_halo_small_kernelI(?:DF16b|f|NS_5fp8_tE)Li(\d+)ELi(\d)E", k) or re.search(r"conv_halo_small_kernel<.*?(\d+), (\d),", k)
         variant = 5000 + int(mh.group(2)) * 16 if mh else 5000
+    elif "stem_down_kernel" in k:
+        variant = 8064
     elif "conv_halo_kernel" in k:
-        mh = re.search(r"conv_halo_kernelI(?:DF16b|f)Li(\d)ELb(\d)ELb(\d)E", k)
-        mh2 = re.search(r"conv_halo_kernel<.*?(\d), (true|false), (true|false)>", k)
+        # <T, NF, SQ, S2, FC, TO, CV1> (mangled or demangled); CV1 = fused bottleneck (7064)
+        mh = re.search(r"conv_halo_kernelI(?:DF16b|f|NS_5fp8_tE)Li(\d)ELb(\d)ELb(\d)ELi(\d+)E(?:DF16b|f|NS_5fp8_tE|S1_)Lb(\d)E", k)
+        mh2 = re.search(r"conv_halo_kernel<[^,]+, (\d), (true|false), (true|false), (\d+), [^,]+, (true|false)>", k)
         if mh:
-            variant = (6000 if mh.group(3) == "1" else 4000) + int(mh.group(1)) * 16
+            variant = 7064 if mh.group(5) == "1" else (6000 if mh.group(3) == "1" else 4000) + int(mh.group(1)) * 16
         elif mh2:
-            variant = (6000 if mh2.group(3) == "true" else 4000) + int(mh2.group(1)) * 16
+            variant = 7064 if mh2.group(5) == "true" else (6000 if mh2.group(3) == "true" else 4000) + int(mh2.group(1)) * 16
     elif "conv_igemm" in k:
         variant = 1000
     # bytes: counters are in KB; FETCH_SIZE x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section)
@@ -48,5 +51,7 @@ for v in out.values():
         by_variant[str(v["variant"])]["hbm_bytes"] += v["hbm_bytes_per_launch"] * v["launches"]
 for v in by_variant.values():
     v["hbm_bytes_per_launch"] = v["hbm_bytes"] / v["launches"]
-print(json.dumps(dict(note="FETCH_SIZE*2 + WRITE_SIZE, KB -> bytes; bench.py --steps 2 --warmup 1 (+2 calibration forwards of 2 frames)",
+total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+print(json.dumps(dict(note="FETCH_SIZE*2 + WRITE_SIZE, KB -> bytes; bench.py --steps 2 --warmup 1 --no-graph (+ calibration forwards of 2 frames, + the timing-bucket passes of bench.py)",
+                      total_hbm_bytes_all_kernels=total,
                       by_variant=by_variant, kernels=out), indent=1))
