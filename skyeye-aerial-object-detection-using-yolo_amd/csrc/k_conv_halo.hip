@@ -501,6 +501,8 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     for (;;) {
         int chunk = 0, q = 0;
         dbg_stamp(a, stamps, nth, 0);
+        if ((SKY_DBG(a) & 256) && nth == 1 && threadIdx.x == 0) stamps[60] = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference clock
+        if ((SKY_DBG(a) & 256) && nth == 0 && threadIdx.x == 0) { stamps[56] = __builtin_amdgcn_s_memtime(); stamps[57] = __builtin_amdgcn_s_memrealtime(); }
         for (int g = 0; g < G; ++g) {
             const TapStep st = tap_step<S2>(q);
             if (st.newhalo && g > 0) {
@@ -535,6 +537,8 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
         dbg_stamp(a, stamps, nth, 41);
         if (!(SKY_DBG(a) & 8)) epilogue_act(bimg, y0, x0);
         dbg_stamp(a, stamps, nth, 42);
+        if ((SKY_DBG(a) & 256) && nth == 1 && threadIdx.x == 0) stamps[61] = __builtin_amdgcn_s_memrealtime();
+        if ((SKY_DBG(a) & 256) && nth == 0 && threadIdx.x == 0) { stamps[58] = __builtin_amdgcn_s_memtime(); stamps[59] = __builtin_amdgcn_s_memrealtime(); }
         if ((SKY_DBG(a) & 256) && nth == 1) {
             wait_vmcnt0();
             dbg_stamp(a, stamps, nth, 43);
@@ -546,6 +550,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     if ((SKY_DBG(a) & 256) && a.raw && nth >= 2 && threadIdx.x == 0 && blockIdx.y == 0) {
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.raw) + (size_t)blockIdx.x * 64;
         for (int k = 0; k < 44; ++k) dst[k] = stamps[k];
+        for (int k = 56; k < 62; ++k) dst[k] = stamps[k];
     }
 }
 
@@ -1033,6 +1038,15 @@ static hipError_t halo_launch(const ConvArgs& a0, hipStream_t s, int n_cu)
                 fprintf(stderr, "halo timeline over %d workgroups (NF=%d S2=%d FC=%d), mean shader clocks since tile start:\n", cnt, NF, (int)S2, FC);
                 for (int k = 0; k < 44; ++k)
                     if (sum[k] > 0) fprintf(stderr, "  [%2d] %9.0f\n", k, sum[k] / (cnt ? cnt : 1));
+                double rt = 0;                 // shader clock held during the tile: cycles / (100 MHz ticks) x 100 MHz
+                for (int w = 0; w < gx; ++w)
+                    if (h[w * 64] && h[w * 64 + 42] && h[w * 64 + 61] > h[w * 64 + 60]) rt += (double)(h[w * 64 + 61] - h[w * 64 + 60]);
+                if (rt > 0) fprintf(stderr, "  shader clock over the tile: %.0f MHz\n", sum[42] / rt * 100.0);
+                double c0 = 0, r0 = 0;
+                int n0 = 0;
+                for (int w = 0; w < gx; ++w)
+                    if (h[w * 64 + 58] > h[w * 64 + 56] && h[w * 64 + 59] > h[w * 64 + 57]) { c0 += (double)(h[w * 64 + 58] - h[w * 64 + 56]); r0 += (double)(h[w * 64 + 59] - h[w * 64 + 57]); ++n0; }
+                if (n0) fprintf(stderr, "  FIRST tile (every CU holds two workgroups): %.0f cycles, %.2f us, shader clock %.0f MHz\n", c0 / n0, r0 / n0 / 100.0, c0 / r0 * 100.0);
             }
         }
     }

@@ -117,3 +117,21 @@ def test_bf16_vs_fp32_engine_post_nms_at_b32_1280():
     record_agreement("skyeye_s B=32 @1280 bf16 vs fp32 engine (post-NMS)", boxes_ref=n_ref, matched_iou50=m50, matched_iou90=m90, mean_iou=miou)
     assert n_ref > 500
     assert m50 > 0.85 and miou > 0.9, (m50, m90, miou)
+
+
+def test_views_of_2gib_and_more_run_as_batch_slices():
+    """skyeye_l's 64-channel 768 x 768 maps at B = 32 (1536 x 1536 frames) exceed the 32-bit byte offsets of the buffer
+    descriptors: the engine runs such convolutions as several launches over batch slices (engine.cpp: run).  A 1x1 and a 3x3
+    (+ residual) over a 2.4 GB tensor equal the same frames run in small batches, bit for bit."""
+    import skyeye.core.models as M
+    from helpers import load_seeded
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(34, 64, 768, 768, device="cuda", generator=g)                  # 34 x 768 x 768 x 64 bf16 = 2.57 GB per tensor
+    for mod in (M.ConvolutionBlock(64, 64, 1, 1), M.BottleneckBlock(64, 64, shortcut=True, expansion=1.0)):
+        m = load_seeded(mod, 3).set_precision("bf16")
+        y = m(x)
+        assert bool(torch.isfinite(y).all())
+        for i in (0, 17, 33):
+            one = m(x[i:i + 1].contiguous())
+            assert torch.equal(one[0], y[i]), f"{type(mod).__name__}: frame {i} of the sliced run differs"
+        del y

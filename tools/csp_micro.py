@@ -11,7 +11,8 @@ c = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else 160
 prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 m = CSPBlock(c, c, num_blocks=3).eval().set_precision(prec)
-x = torch.randn(32, c, hw, hw, device="cuda")
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+x = torch.randn(B, c, hw, hw, device="cuda")
 m(x)
 h = m._engine([x])
 outs = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in h.output_shapes()]
