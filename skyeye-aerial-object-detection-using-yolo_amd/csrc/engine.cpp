@@ -427,6 +427,7 @@ struct ConvOpt {
     const TV* res = nullptr;
     bool up2 = false;
     int cin_real = -1;   // when the stored tensor has zero-padded channels (stem)
+    int out_dt = -1;     // element type of a freshly allocated output (default: the engine's activation type)
 };
 
 // ConvolutionBlock (blocks.py:10-41)
@@ -446,7 +447,7 @@ static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cou
         const int eh = o.up2 ? 2 * Ho : Ho, ew = o.up2 ? 2 * Wo : Wo;
         if (y.C != cout || y.H != eh || y.W != ew || y.B != x.B) throw Error(SKY_ERR_SHAPE, p + ": output slot geometry mismatch");
     } else {
-        y = c.new_tensor(x.B, o.up2 ? 2 * Ho : Ho, o.up2 ? 2 * Wo : Wo, cout);
+        y = c.new_tensor(x.B, o.up2 ? 2 * Ho : Ho, o.up2 ? 2 * Wo : Wo, cout, o.out_dt);
     }
     Op op;
     op.kind = OP_CONV;
@@ -512,7 +513,7 @@ static TV bottleneck(Ctx& c, const std::string& p, const TV& x, int cin, int cou
 
 // CSPBlock (blocks.py:93-123): cv3(cat(bottlenecks(cv1(x)), cv2(x)))
 static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int n, bool shortcut, float expansion,
-              const TV* out_into = nullptr)
+              const TV* out_into = nullptr, int out_dt = -1)
 {
     const int h = (int)(cout * expansion);
     c.need(p + "cv1.conv.weight", {h, cin, 1, 1});
@@ -553,6 +554,7 @@ static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int 
     }
     ConvOpt o;
     o.out_into = out_into;
+    o.out_dt = out_dt;
     return conv_block(c, p + "cv3.", cat, 2 * h, cout, 1, 1, true, o);
 }
 
@@ -942,17 +944,20 @@ static void neck(Ctx& c, const std::string& p, const NeckSlots& n, int c3, int c
     lateral("lateral_conv4.", p4, c4, c3, Ctx::slice(n.cat_p3m, 0, c3), p3.H, p3.W);   // :211,218
     TV p4p_slot = Ctx::slice(n.cat_p4c, c3, c4);
     csp(c, p + "fpn_conv4.", n.cat_p4m, 2 * c4, c4, 3, true, 0.5f, &p4p_slot);          // :216
-    out[0] = csp(c, p + "fpn_conv3.", n.cat_p3m, 2 * c3, c3, 3, true, 0.5f);            // :220
+    // fp8 engine: the three maps the detection levels read stay bf16 (the last rounding before the box regression is bf16's, and
+    // the detection convolutions then run in bf16 like the stem); the stride-2 convolutions that also read them write fp8 again
+    const int odt = c.e.dtype == SKY_FP8 ? (int)SKY_BF16 : -1;
+    out[0] = csp(c, p + "fpn_conv3.", n.cat_p3m, 2 * c3, c3, 3, true, 0.5f, nullptr, odt);            // :220
     ConvOpt d3;
     TV d3_slot = Ctx::slice(n.cat_p4c, 0, c3);
     d3.out_into = &d3_slot;
     conv_block(c, p + "downsample3.", out[0], c3, c3, 3, 2, true, d3);                  // :223
-    out[1] = csp(c, p + "pan_conv4.", n.cat_p4c, c3 + c4, c4, 3, true, 0.5f);           // :225
+    out[1] = csp(c, p + "pan_conv4.", n.cat_p4c, c3 + c4, c4, 3, true, 0.5f, nullptr, odt);           // :225
     ConvOpt d4;
     TV d4_slot = Ctx::slice(n.cat_p5c, 0, c4);
     d4.out_into = &d4_slot;
     conv_block(c, p + "downsample4.", out[1], c4, c4, 3, 2, true, d4);                  // :227
-    out[2] = csp(c, p + "pan_conv5.", n.cat_p5c, c4 + c5, c5, 3, true, 0.5f);           // :229
+    out[2] = csp(c, p + "pan_conv5.", n.cat_p5c, c4 + c5, c5, 3, true, 0.5f, nullptr, odt);           // :229
 }
 
 // DetectionHead.forward + process_detections (detector.py:61-145) -> outputs [det, raw_0, ...]

@@ -1123,7 +1123,7 @@ static hipError_t halo_small_dispatch(int cb, int nb, const ConvArgs& a, hipStre
 static bool halo_types_ok(int dtype, const ConvArgs& a, bool narrow)
 {
     const int odt = a.out_dt < 0 ? dtype : a.out_dt;
-    return odt == dtype || (narrow && dtype == 1 && odt == 2);
+    return odt == dtype || (dtype == 1 && odt == 2 && (narrow || a.stride == 2));     // bf16 -> fp8: narrow kernels, stride-2 tile kernel
 }
 
 // the checks that route a convolution to the narrow-input kernel (the only one with a raw-frame loader)
@@ -1240,7 +1240,10 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     hipError_t e;
 #define SKY_HALO(T, S2V) (nb == 128 ? (sq ? halo_launch<T, 8, true, S2V>(a, s, n_cu) : halo_launch<T, 8, false, S2V>(a, s, n_cu)) \
                                     : (sq ? halo_launch<T, 4, true, S2V>(a, s, n_cu) : halo_launch<T, 4, false, S2V>(a, s, n_cu)))
-    if (a.stride == 2) {
+    if (a.stride == 2 && dtype == 1 && odt == 2) {      // the fp8 engine's stride-2 convolutions behind its bf16 neck outputs
+        e = nb == 128 ? (sq ? halo_launch<__bf16, 8, true, true, 0, fp8_t>(a, s, n_cu) : halo_launch<__bf16, 8, false, true, 0, fp8_t>(a, s, n_cu))
+                      : (sq ? halo_launch<__bf16, 4, true, true, 0, fp8_t>(a, s, n_cu) : halo_launch<__bf16, 4, false, true, 0, fp8_t>(a, s, n_cu));
+    } else if (a.stride == 2) {
         e = dtype == 0 ? SKY_HALO(float, true) : dtype == 1 ? SKY_HALO(__bf16, true) : SKY_HALO(fp8_t, true);
     } else if (dtype != 2 && a.f2_w && nb == 64 && a.Cout == 64 && a.f2_cin == 64 && a.f2_cout == 64 && a.f2_koff == 0 && a.f2_out_bytes) {
         // the 1x1 convolution that follows (the next bottleneck's cv1) runs in this kernel's epilogue

@@ -485,10 +485,10 @@ static hipError_t stream_dispatch_fused(const StreamPlan& p, const ConvArgs& a, 
     return KT == 4 ? stream_launch<T, 1, 2, 8, false, true, 4, false, 64>(a, s, n_cu) : hipErrorNotSupported;
 }
 
-template <typename T, int KS, int KT>
+template <typename T, int KS, int KT, typename TO = T>
 static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs& a, hipStream_t s, int n_cu, int* fused = nullptr)
 {
-    if constexpr (sizeof(T) >= 2) {
+    if constexpr (sizeof(T) >= 2 && std::is_same<T, TO>::value) {
         if (KS == 1 && utap && !p.ring && a.f2_w && a.f2_koff == 0 && a.f2_cin == a.f2_cout && p.nf * 16 == a.Cout &&
             ((p.nf == 4 && a.f2_cin == 32) || (p.nf == 8 && a.f2_cin == 64)) && !a.up2 && !a.res) {
             const size_t extra = (size_t)a.f2_cin * a.f2_cin * sizeof(T) + a.f2_cin * 4;
@@ -503,38 +503,38 @@ static hipError_t stream_dispatch(const StreamPlan& p, bool utap, const ConvArgs
         }
     }
     if (!utap) {   // narrow inputs (the stem): per-lane tap, only built for the 32-channel tile
-        if (KS == 3 && !p.ring && p.nf == 2) return stream_launch<T, 3, 4, 2, false, false, KT>(a, s, n_cu);
+        if constexpr (KS == 3) { if (!p.ring && p.nf == 2) return stream_launch<T, 3, 4, 2, false, false, KT, false, 0, TO>(a, s, n_cu); }
         if constexpr (sizeof(T) == 1 && KS == 1 && KT == 1) {
             // 1x1 over 32 fp8 channels (32 bytes per pixel: half a K-step; the other half is masked per lane): the fp8 engine's
             // stage-1 bottleneck cv1, which would otherwise fall to the tile kernel
             if (!p.ring && (size_t)a.Cin * sizeof(T) <= 64) {
                 switch (p.nf) {
-                    case 8: return stream_launch<T, 1, 2, 8, false, false, 1, true>(a, s, n_cu);
-                    case 4: return stream_launch<T, 1, 2, 4, false, false, 1, true>(a, s, n_cu);
-                    default: return stream_launch<T, 1, 4, 2, false, false, 1, true>(a, s, n_cu);
+                    case 8: return stream_launch<T, 1, 2, 8, false, false, 1, true, 0, TO>(a, s, n_cu);
+                    case 4: return stream_launch<T, 1, 2, 4, false, false, 1, true, 0, TO>(a, s, n_cu);
+                    default: return stream_launch<T, 1, 4, 2, false, false, 1, true, 0, TO>(a, s, n_cu);
                 }
             }
         }
         return hipErrorNotSupported;
     }
-    if (p.ring) return KT == 4 ? stream_launch<T, KS, 2, 8, true, true, 4>(a, s, n_cu) : hipErrorNotSupported;
+    if (p.ring) return KT == 4 ? stream_launch<T, KS, 2, 8, true, true, 4, false, 0, TO>(a, s, n_cu) : hipErrorNotSupported;
     if (KS == 1 && KT < 4 && (size_t)a.Cin * sizeof(T) <= 256) {   // one slab of K: fetch only its real K-steps
         switch (p.nf) {
-            case 8: return stream_launch<T, 1, 2, 8, false, true, KT, true>(a, s, n_cu);
-            case 4: return stream_launch<T, 1, 2, 4, false, true, KT, true>(a, s, n_cu);
-            default: return stream_launch<T, 1, 4, 2, false, true, KT, true>(a, s, n_cu);
+            case 8: return stream_launch<T, 1, 2, 8, false, true, KT, true, 0, TO>(a, s, n_cu);
+            case 4: return stream_launch<T, 1, 2, 4, false, true, KT, true, 0, TO>(a, s, n_cu);
+            default: return stream_launch<T, 1, 4, 2, false, true, KT, true, 0, TO>(a, s, n_cu);
         }
     }
     switch (p.nf) {
         case 8:
-            if (KT == 4) return stream_launch<T, KS, 2, 8, false, true, 4>(a, s, n_cu);
+            if (KT == 4) return stream_launch<T, KS, 2, 8, false, true, 4, false, 0, TO>(a, s, n_cu);
             [[fallthrough]];   // two loop bodies + 128 channels spill: use two 64-channel tiles instead
-        case 4: return stream_launch<T, KS, 2, 4, false, true, KT>(a, s, n_cu);
-        default: return stream_launch<T, KS, 4, 2, false, true, KT>(a, s, n_cu);
+        case 4: return stream_launch<T, KS, 2, 4, false, true, KT, false, 0, TO>(a, s, n_cu);
+        default: return stream_launch<T, KS, 4, 2, false, true, KT, false, 0, TO>(a, s, n_cu);
     }
 }
 
-template <typename T>
+template <typename T, typename TO = T>
 static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipStream_t s, int n_cu, int* fused)
 {
     const int Cb = a.Cin * (int)sizeof(T);
@@ -544,17 +544,20 @@ static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipS
     const int kt = ((Kb - (nslab - 1) * SLAB) + 63) >> 6;
     if (a.ks == 1) {
         switch (kt) {
-            case 4: return stream_dispatch<T, 1, 4>(p, utap, a, s, n_cu, fused);
-            case 2: return stream_dispatch<T, 1, 2>(p, utap, a, s, n_cu, fused);
-            case 1: return stream_dispatch<T, 1, 1>(p, utap, a, s, n_cu, fused);
+            case 4: return stream_dispatch<T, 1, 4, TO>(p, utap, a, s, n_cu, fused);
+            case 2: return stream_dispatch<T, 1, 2, TO>(p, utap, a, s, n_cu, fused);
+            case 1: return stream_dispatch<T, 1, 1, TO>(p, utap, a, s, n_cu, fused);
             default: return hipErrorNotSupported;
         }
     }
-    switch (kt) {
-        case 4: return stream_dispatch<T, 3, 4>(p, utap, a, s, n_cu);
-        case 2: return stream_dispatch<T, 3, 2>(p, utap, a, s, n_cu);
-        case 1: return stream_dispatch<T, 3, 1>(p, utap, a, s, n_cu);
-        default: return hipErrorNotSupported;
+    if constexpr (!std::is_same<T, TO>::value) return hipErrorNotSupported;      // mixed types: 1x1 only
+    else {
+        switch (kt) {
+            case 4: return stream_dispatch<T, 3, 4>(p, utap, a, s, n_cu);
+            case 2: return stream_dispatch<T, 3, 2>(p, utap, a, s, n_cu);
+            case 1: return stream_dispatch<T, 3, 1>(p, utap, a, s, n_cu);
+            default: return hipErrorNotSupported;
+        }
     }
 }
 
@@ -563,10 +566,14 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 {
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     if (a.src_mode) return hipErrorNotSupported;
-    if (a.out_dt >= 0 && a.out_dt != dtype) return hipErrorNotSupported;      // mixed types (the fp8 engine's bf16 stem): tile kernel
+    const bool mixed = a.out_dt >= 0 && a.out_dt != dtype;
+    // mixed types: fp8 operands with a bf16 output (the fp8 engine's last neck convolutions, 1x1, no residual) run here; the rest
+    // (its bf16 stem on shapes the narrow halo kernel leaves) on the tile kernel
+    if (mixed && !(dtype == 2 && a.out_dt == 1 && a.ks == 1 && !a.f2_w)) return hipErrorNotSupported;
     const StreamPlan p = stream_plan(dtype, a);
     if (p.nf == 0) return hipErrorNotSupported;
-    const hipError_t e = dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu, fused)
+    const hipError_t e = mixed ? stream_dispatch_t<fp8_t, __bf16>(p, a, s, n_cu, fused)
+                         : dtype == 0 ? stream_dispatch_t<float>(p, a, s, n_cu, fused)
                          : dtype == 1 ? stream_dispatch_t<__bf16>(p, a, s, n_cu, fused) : stream_dispatch_t<fp8_t>(p, a, s, n_cu, fused);
     if (e == hipSuccess && variant) *variant = (p.ring ? 3000 : 2000) + p.nf * 16;
     return e;
