@@ -1586,6 +1586,7 @@ static unsigned read_plan_opts()
     if (env("SKY_ATTN_VALU")) o |= OPT_ATTN_VALU;
     if (env("SKY_NO_FUSE_CV1")) o |= OPT_NO_FUSE_CV1;
     if (env("SKY_NO_STEM_DOWN")) o |= OPT_NO_STEM_DOWN;
+    if (env("SKY_NO_WINATTN")) o |= OPT_NO_WINATTN;
     if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
     return o;
 }

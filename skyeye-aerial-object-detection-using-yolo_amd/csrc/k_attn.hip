@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
                     if (bias) add = bias[((long)h * N + q) * N + key];
                     if (mask) add += mask[((long)(b % nW) * N + q) * N + key];
                 }
-                sT[T][r] = key < N ? sT[T][r] * sl2 + add * 1.4426950408889634f : -INFINITY;
+                sT[T][r] = key < N ? __builtin_fmaf(sT[T][r], sl2, add * 1.4426950408889634f) : -INFINITY;
                 bm = sT[T][r] > bm ? sT[T][r] : bm;
             }
         bm = fmaxf(bm, __shfl_xor(bm, 16));
@@ -280,6 +280,165 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 8 x 8 window core
+// WindowedSelfAttention over 64-token windows with 32-channel heads (attention.py:377-392; every windowed layer of the
+// detector: heads = C / 32), bf16 engine.  The general flash kernel above spends a workgroup, two barriers and a scattered
+// V^T staging on 64 x 64 x 32 scores; here ONE WAVE owns a (window, head) pair and walks windows persistently:
+//   * the relative position bias of the wave's head (64 values per lane, x log2 e) is loaded once and stays in registers;
+//   * Q and K fragments come straight from global in operand order (16 bytes per lane), no LDS;
+//   * V is written row-major into a wave-private 4 KB LDS image with 16-byte stores and read back transposed with
+//     ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group): the A operand of O^T = V^T P^T in the key order of
+//     this lane's own probabilities, as in the general kernel;
+//   * no workgroup barrier anywhere; the next window's loads are requested before the current window's arithmetic.
+// The four waves of a workgroup take four neighbouring heads of the same windows, so their 64-byte head slices share
+// cache lines.  Arithmetic and its order are those of attention_mfma_kernel<32, true> with one key block: results are
+// bit-identical (tests/test_gpu_attention_mfma.py).
+typedef __attribute__((ext_vector_type(4))) short s16x4_att_t;
+
+__global__ void __launch_bounds__(256) window_attention_kernel(const __bf16* __restrict__ qkv, int ldq, __bf16* __restrict__ out, int ldo, int G,
+                                                               int C, float scale, const float* __restrict__ bias, int ws, int mh, int mw)
+{
+    constexpr int D = 32, N = 64;
+    __shared__ __attribute__((aligned(16))) char vlds[4][N * 64];      // per wave: V [64 keys][32 channels], 32-byte halves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;        // swapped on keys with bit 2 set (conflict-free tr reads)
+    const int n = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y * 4 + wave;
+    char* vl = vlds[wave];
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    float bl[4][4][4];                                                 // bias[h][query qt*16+n][key T*16+4g+r] * log2 e
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x4_t v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (bias) v = *reinterpret_cast<const f32x4_t*>(bias + ((long)h * N + qt * 16 + n) * N + T * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bl[qt][T][r] = v[r] * LOG2E;
+        }
+    const float sl2 = scale * LOG2E;
+
+    // V staging: lane -> key (lane >> 2) + 16 i, 16-byte chunk lane & 3
+    const int vkey = lane >> 2, vc = lane & 3;
+    // transposed reads: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the 4-key x 16-channel block
+    const int tq = n >> 2, tp = n & 3;
+
+    // token (i*16 + n) of a window sits at window_base + toff[i] pixel rows; the base is wave-uniform
+    int toff[4], voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = i * 16 + n, tv = i * 16 + vkey;
+        toff[i] = ws > 0 ? (t / ws) * mw + t % ws : t;
+        voff[i] = ws > 0 ? (tv / ws) * mw + tv % ws : tv;
+    }
+    const int nwx = ws > 0 ? mw / ws : 1, nwy = ws > 0 ? mh / ws : 1;
+    auto window_base = [&](int w_) -> int {
+        if (ws <= 0) return w_ * N;
+        const int wx = w_ % nwx, t = w_ / nwx, wy = t % nwy, b = t / nwy;
+        return (b * mh + wy * ws) * mw + wx * ws;
+    };
+    u32x4_t qf[4], kf[4], vv[4];
+    int row[4];
+    auto fetch = [&](int w_, u32x4_t (&q_)[4], u32x4_t (&k_)[4], u32x4_t (&v_)[4], int (&row_)[4]) {
+        const int base = window_base(w_);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            row_[i] = base + toff[i];
+            const __bf16* p = qkv + (long)row_[i] * ldq + h * D + g * 8;
+            q_[i] = *reinterpret_cast<const u32x4_t*>(p);
+            k_[i] = *reinterpret_cast<const u32x4_t*>(p + C);
+            v_[i] = *reinterpret_cast<const u32x4_t*>(qkv + (long)(base + voff[i]) * ldq + 2 * C + h * D + vc * 8);
+        }
+    };
+    int w = blockIdx.x;
+    if (w < G) fetch(w, qf, kf, vv, row);
+    for (; w < G; w += gridDim.x) {
+        // ---- V image of this window, then its transposed fragments ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = i * 16 + vkey;
+            *reinterpret_cast<u32x4_t*>(vl + key * 64 + ((vc ^ (((key >> 2) & 1) << 1)) << 4)) = vv[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32x4_t vf[2][2];                                              // [K-step of 32 keys][16-channel tile]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int krow = (2 * ks + e) * 16 + 4 * g + tq;   // keys (2ks + e)*16 + 4g .. +3: elements 4e .. 4e+3
+                    const int c = t * 2 + (tp >> 1);
+                    const char* a = vl + krow * 64 + ((c ^ ((g & 1) << 1)) << 4) + 8 * (tp & 1);
+                    const s16x4_att_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_att_t*)a);
+                    const uint2 u = __builtin_bit_cast(uint2, r);
+                    vf[ks][t][2 * e] = u.x;
+                    vf[ks][t][2 * e + 1] = u.y;
+                }
+        __builtin_amdgcn_wave_barrier();
+        // ---- next window's operands ----
+        u32x4_t nq[4], nk[4], nv[4];
+        int nrow[4];
+        const int wn = w + gridDim.x;
+        if (wn < G) fetch(wn, nq, nk, nv, nrow);
+        // ---- four 16-query tiles ----
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            f32x4_t sT[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+                sT[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, kf[T]), __builtin_bit_cast(bf16x8_att_t, qf[qt]),
+                                                                f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            float bm = -INFINITY;
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sT[T][r] = __builtin_fmaf(sT[T][r], sl2, bl[qt][T][r]);
+                    bm = sT[T][r] > bm ? sT[T][r] : bm;
+                }
+            bm = fmaxf(bm, __shfl_xor(bm, 16));
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float mn = bm > -INFINITY ? bm : -INFINITY;
+            float bs = 0.0f;
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sT[T][r] = __builtin_amdgcn_exp2f(sT[T][r] - mn);
+                    bs += sT[T][r];
+                }
+            bs += __shfl_xor(bs, 16);
+            bs += __shfl_xor(bs, 32);
+            f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4_t pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4_t& src = sT[2 * ks + (e >> 1)];
+                    pf[e] = pack_bf16x2(src[(e & 1) * 2], src[(e & 1) * 2 + 1]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, vf[ks][t]), __builtin_bit_cast(bf16x8_att_t, pf), o[t], 0, 0, 0);
+            }
+            const float inv = 1.0f / bs;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint2 wv;
+                wv.x = pack_bf16x2(o[t][0] * inv, o[t][1] * inv);
+                wv.y = pack_bf16x2(o[t][2] * inv, o[t][3] * inv);
+                *reinterpret_cast<uint2*>(out + (long)row[qt] * ldo + h * D + t * 16 + 4 * g) = wv;
+            }
+        }
+        if (wn < G) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { qf[i] = nq[i]; kf[i] = nk[i]; vv[i] = nv[i]; row[i] = nrow[i]; }
+        }
+    }
+}
+
 template <typename T>
 static hipError_t attention_t(const void* qkv, int ldq, void* out, int ldo, int G, int N, int C, int heads, float scale, const float* bias,
                               const float* mask, int nW, int ws, int mh, int mw, hipStream_t s)
@@ -304,6 +463,14 @@ hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int 
 {
     const int D = heads > 0 ? C / heads : 0;
     const bool no_mfma = (opts & OPT_ATTN_VALU) != 0;                     // A/B switch, fixed at plan time
+    if (dtype != 0 && !no_mfma && !(opts & OPT_NO_WINATTN) && (ws > 0 || bias) && !mask && N == 64 && D == 32 && heads % 4 == 0 && ldq % 8 == 0 &&
+        ldo % 4 == 0 && C % 8 == 0 && (ws <= 0 || (ws == 8 && mh % 8 == 0 && mw % 8 == 0))) {
+        const int gy = heads / 4;
+        const int gx = G < 512 / gy ? G : (512 / gy > 0 ? 512 / gy : 1);   // two persistent workgroups per CU over all head groups
+        hipLaunchKernelGGL(window_attention_kernel, dim3(gx, gy), dim3(256), 0, s, (const __bf16*)qkv, ldq, (__bf16*)out, ldo, G, C, scale, bias, ws, mh,
+                           mw);
+        return hipGetLastError();
+    }
     if (dtype != 0 && !no_mfma && N >= 64 && (D == 32 || D == 64 || D == 128) && ldq % 8 == 0 && ldo % 4 == 0 && C % 8 == 0) {
         const dim3 grid((N + 63) / 64, heads, G);
         const bool win = ws > 0 || bias || mask;

@@ -31,6 +31,7 @@ enum PlanOpt : unsigned {
     OPT_ATTN_VALU = 1u << 11,        // SKY_ATTN_VALU        exact attention core for bf16 too
     OPT_NO_FUSE_CV1 = 1u << 12,      // SKY_NO_FUSE_CV1      bottleneck cv1 as its own launch (default: fused into the 3x3 where covered)
     OPT_NO_STEM_DOWN = 1u << 13,     // SKY_NO_STEM_DOWN     stem and first stride-2 convolution as two launches (default: one kernel where covered)
+    OPT_NO_WINATTN = 1u << 14,       // SKY_NO_WINATTN       8 x 8 windows on the general flash kernel (default: the one-wave-per-(window, head) kernel)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 

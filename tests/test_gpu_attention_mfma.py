@@ -92,3 +92,62 @@ def test_mfma_windowed_attention_matches_oracle_and_valu_core(case):
     assert np.isfinite(y_mfma).all()
     assert float(np.abs(y_mfma - ref).max()) <= 4e-2 * scale
     assert float(np.abs(y_mfma - y_valu).max()) <= 2e-2 * scale
+
+
+# 8 x 8 windows with 32-channel heads, heads % 4 == 0, no mask: window_attention_kernel (one wave per (window, head), bias in
+# registers, V through a transposed LDS read).  Same arithmetic in the same order as the general flash kernel: bit-identical.
+WIN_CASES = [(128, 4, 8), (256, 8, 5), (128, 4, 1), (512, 16, 3)]     # (dim, heads, B_)
+
+
+@pytest.mark.parametrize("case", WIN_CASES, ids=["d%d_h%d_n%d" % c for c in WIN_CASES])
+def test_window_kernel_matches_oracle_and_is_bit_identical_to_flash_kernel(case):
+    dim, heads, Bw = case
+    O = _oracle()
+    m = load_seeded(M.WindowedSelfAttention(dim, 8, heads), 63).set_precision("bf16")
+    P = seeded_state_for(m, 63)
+    x = seeded_input("win.x.%d.%d" % (dim, Bw), (Bw, 64, dim), 15, -1.0, 1.0)
+    ref = O.windowed_self_attention(P, "", x, 8, heads, None)
+    xg = torch.from_numpy(x).cuda()
+
+    def run(switch):
+        if switch:
+            os.environ[switch] = "1"
+        try:
+            y = m(xg)
+            torch.cuda.synchronize()
+            return y.cpu().numpy()
+        finally:
+            if switch:
+                os.environ.pop(switch, None)
+
+    y_win, y_flash, y_valu = run(None), run("SKY_NO_WINATTN"), run("SKY_ATTN_VALU")
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(y_win).all()
+    assert float(np.abs(y_win - ref).max()) <= 4e-2 * scale
+    assert float(np.abs(y_win - y_valu).max()) <= 2e-2 * scale
+    assert np.array_equal(y_win, y_flash), "window kernel differs from the general flash kernel"
+
+
+def test_window_kernel_on_a_feature_map_is_bit_identical_to_flash_kernel():
+    """The detector's wiring: windows addressed in place on a [B, H, W, C] map (config 3, head_attention; 4 and 8 heads)."""
+    from helpers import build_detector, detector_params, variant_cfg
+    from seeded import seeded_scene
+    m = build_detector(variant_cfg("skyeye_s_ha"))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params("skyeye_s_ha").items()}, strict=True)
+    m.eval().set_precision("bf16")
+    x = torch.from_numpy(seeded_scene(3, 256, 384, 80)).cuda()
+
+    def run(switch):
+        if switch:
+            os.environ[switch] = "1"
+        try:
+            det, raw = m(x)
+            torch.cuda.synchronize()
+            return [det.cpu().numpy()] + [r.cpu().numpy() for r in raw]
+        finally:
+            if switch:
+                os.environ.pop(switch, None)
+
+    a, b = run(None), run("SKY_NO_WINATTN")
+    for u, v in zip(a, b):
+        assert np.isfinite(u).all() and np.array_equal(u, v)
