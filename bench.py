@@ -115,7 +115,8 @@ FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded
     ("halo3x3", "conv_halo_kernel: 3x3 halo tile + weight ring (stride 1 and 2)", lambda v: 4000 <= v < 5000 or 6000 <= v < 7000),
     ("halo_narrow", "conv_halo_small_kernel: stem / narrow-input 3x3, K resident", lambda v: 5000 <= v < 6000),
     ("halo_cv1", "conv_halo_kernel<CV1>: bottleneck 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
-    ("stem_down", "stem_down_kernel: frames -> FocusBlock 3x3 -> 3x3 stride 2 in one kernel", lambda v: 8000 <= v < 9000),
+    ("stem_down", "stem_down_kernel: frames -> FocusBlock 3x3 -> 3x3 stride 2 in one kernel", lambda v: 8000 <= v < 8500),
+    ("csp_stage", "csp_stage_kernel: CSPBlock(64, 64, 1) = cv1|cv2 -> 1x1 -> 3x3 + shortcut -> cv3 in one kernel", lambda v: 8500 <= v < 9000),
     ("stream_resident", "conv_stream_kernel: 1x1 (and narrow 3x3), weights resident in LDS", lambda v: 2000 <= v < 3000),
     ("stream_ring", "conv_stream_kernel: large-K 1x1, weight ring", lambda v: 3000 <= v < 4000),
     ("tile", "conv_igemm_kernel: detection levels (N = 45) + fallback shapes", lambda v: 1000 <= v < 2000),

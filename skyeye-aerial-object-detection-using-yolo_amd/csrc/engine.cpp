@@ -79,6 +79,9 @@ struct Op {
     int wid1 = -1;         // fused BottleneckBlock: packed weights of cv1 (the 1x1 computed on the halo tile of the 3x3, k_conv_halo.hip CV1)
     int c1_res = 0;        // ... with the shortcut x + cv2(cv1(x))
     int stem_down = 0;     // this FocusBlock convolution and the stride-2 convolution behind it can run as ONE kernel (k_stem_down.hip)
+    int csp_stage = 0;     // cv1|cv2 of a CSPBlock whose whole stage (this op and the next three) can run as ONE kernel (k_csp_stage.hip)
+    int csp_member = 0;    // one of those next three ops: skipped at run time when the stage kernel ran
+    int csp_shortcut = 0;
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 0, up2 = 0;
     int head = 0, level = 0;
     int raw_ext = -1, det_ext = -1;
@@ -555,7 +558,24 @@ static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int 
     ConvOpt o;
     o.out_into = out_into;
     o.out_dt = out_dt;
-    return conv_block(c, p + "cv3.", cat, 2 * h, cout, 1, 1, true, o);
+    TV out = conv_block(c, p + "cv3.", cat, 2 * h, cout, 1, 1, true, o);
+    // One bottleneck, 64 -> 64 channels with 32 hidden (the first stage of skyeye_s): the four ops above stay in the plan (they are
+    // what runs when the stage kernel does not cover the call) and are marked so that run() can replace them by ONE launch of
+    // k_csp_stage.hip.  That kernel writes cv3's output while other tiles still read x: the output buffer is alive from the first op.
+    if (c.emit && n == 1 && !fuse && cin == 64 && cout == 64 && h == 32 && x.dt == SKY_BF16 && out.dt == SKY_BF16 && out.buf >= 0 &&
+        out.buf != x.buf && !(c.e.opts & OPT_NO_CSP_STAGE) && c.e.ops.size() >= 4) {
+        const size_t i0 = c.e.ops.size() - 4;
+        bool plain = c.e.ops[i0].kind == OP_CONV && c.e.ops[i0].out.buf == cat.buf;
+        for (size_t k = i0; k < i0 + 4; ++k) plain = plain && c.e.ops[k].kind == OP_CONV && !c.e.ops[k].fuse_next && !c.e.ops[k].fused_prev;
+        if (plain) {
+            c.e.ops[i0].csp_stage = 1;
+            c.e.ops[i0].csp_shortcut = shortcut ? 1 : 0;
+            for (size_t k = i0 + 1; k < i0 + 4; ++k) c.e.ops[k].csp_member = 1;
+            Buffer& b = c.e.bufs[out.buf];
+            b.first = std::min(b.first, (int)i0);
+        }
+    }
+    return out;
 }
 
 // SPPBlock (blocks.py:126-149), kernel sizes (5, 9, 13) = 5, 5o5, 5o5o5
@@ -1255,6 +1275,7 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     int op_index = 0;
     if (marks) SKY_HIP(hipEventRecord(marks[0], s));
     bool took_next = false;     // the previous op's kernel also computed this (fused_prev) op
+    int skip_csp = 0;           // ops of a CSP stage still to skip (the stage kernel computed them)
     const void* raw_src = nullptr;   // set by a skipped FocusBlock import: the next convolution reads the caller's frames
     int raw_mode = 0;
     bool stem_down_now = false;      // set by a skipped import: the stem op launches the fused stem + stride-2 kernel
@@ -1271,6 +1292,13 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
             return;
         }
         took_next = false;
+        if (op.csp_member && skip_csp > 0) {       // computed by the CSP stage kernel launched at the stage's first op
+            --skip_csp;
+            op.variant = 9000;
+            ++op_index;
+            if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
+            return;
+        }
         switch (op.kind) {
             case OP_IMPORT: {
                 const sky_buffer& src = ins[op.in.ext];
@@ -1343,6 +1371,33 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     op.variant = 8064;
                     took_next = true;                  // the stride-2 convolution behind this op is done too
                     break;
+                }
+                if (op.csp_stage && oi + 3 < e.ops.size() && !amax) {
+                    // CSPBlock(64, 64, n = 1): cv1|cv2, bottleneck cv1, bottleneck cv2 (+ shortcut), cv3 in one launch
+                    const Op &b1 = e.ops[oi + 1], &b2 = e.ops[oi + 2], &c3 = e.ops[oi + 3];
+                    CspStageArgs ca;
+                    memset(&ca, 0, sizeof(ca));
+                    const int b0 = sl_nb >= 0 ? sl_b0 : 0, nb = sl_nb >= 0 ? sl_nb : op.in.B;
+                    ca.in = (const char*)tv_ptr(e, op.in, ins, n_in, outs, n_out) + (size_t)b0 * op.in.H * op.in.W * op.in.ld * 2;
+                    ca.ldi = op.in.ld;
+                    ca.out = (char*)tv_ptr(e, c3.out, ins, n_in, outs, n_out) + (size_t)b0 * op.in.H * op.in.W * c3.out.ld * 2;
+                    ca.ldo = c3.out.ld;
+                    ca.B = nb; ca.H = op.in.H; ca.W = op.in.W; ca.c = op.cin; ca.hidden = b1.cout;
+                    const double ext = ((double)nb * op.in.H * op.in.W - 1.0) * op.in.ld * 2 + (double)op.cin * 2;
+                    ca.in_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;
+                    const DevConv &d12 = e.convs[op.wid], &db1 = e.convs[b1.wid], &db2 = e.convs[b2.wid], &d3 = e.convs[c3.wid];
+                    ca.w12 = d12.w; ca.b12 = d12.bias; ca.kpad12 = d12.Kpad;
+                    ca.wb1 = db1.w; ca.bb1 = db1.bias; ca.kpadb1 = db1.Kpad;
+                    ca.wb2 = db2.w; ca.bb2 = db2.bias; ca.kpadb2 = db2.Kpad;
+                    ca.w3 = d3.w; ca.b3 = d3.bias; ca.kpad3 = d3.Kpad;
+                    ca.shortcut = op.csp_shortcut;
+                    ca.opts = e.opts; ca.device = cf.device; ca.n_cu = e.n_cu;
+                    if (csp_stage_supported(ca)) {
+                        SKY_HIP(launch_csp_stage(ca, s));
+                        op.variant = 8564;
+                        skip_csp = 3;
+                        break;
+                    }
                 }
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
@@ -1587,6 +1642,7 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_FUSE_CV1")) o |= OPT_NO_FUSE_CV1;
     if (env("SKY_NO_STEM_DOWN")) o |= OPT_NO_STEM_DOWN;
     if (env("SKY_NO_WINATTN")) o |= OPT_NO_WINATTN;
+    if (env("SKY_NO_CSP_STAGE")) o |= OPT_NO_CSP_STAGE;
     if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
     return o;
 }
@@ -1701,7 +1757,7 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
     tw.cfg.dtype = SKY_BF16;
     tw.dtype = SKY_BF16;
     tw.weights = e.weights;
-    tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
+    tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN | OPT_NO_CSP_STAGE;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
     plan(tw, geometry_of(n_inputs, inputs));
     if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");
     std::vector<sky_buffer> outs(tw.out_info.size());
@@ -1961,7 +2017,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : "tile", op.variant % 1000);
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)

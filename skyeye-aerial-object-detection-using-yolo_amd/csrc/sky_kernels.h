@@ -32,6 +32,7 @@ enum PlanOpt : unsigned {
     OPT_NO_FUSE_CV1 = 1u << 12,      // SKY_NO_FUSE_CV1      bottleneck cv1 as its own launch (default: fused into the 3x3 where covered)
     OPT_NO_STEM_DOWN = 1u << 13,     // SKY_NO_STEM_DOWN     stem and first stride-2 convolution as two launches (default: one kernel where covered)
     OPT_NO_WINATTN = 1u << 14,       // SKY_NO_WINATTN       8 x 8 windows on the general flash kernel (default: the one-wave-per-(window, head) kernel)
+    OPT_NO_CSP_STAGE = 1u << 15,     // SKY_NO_CSP_STAGE     the first CSP stage as four launches (default: one kernel where covered)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -153,6 +154,27 @@ struct StemDownArgs {
 };
 bool stem_down_supported(const StemDownArgs& a);
 hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);
+
+// CSPBlock(c, c, n = 1) with hidden = c / 2 as one kernel (k_csp_stage.hip); weights in the engine's packing, BN folded
+struct CspStageArgs {
+    const void* in;                // bf16 NHWC view [B, H, W, c] with pixel stride ldi
+    int ldi;
+    unsigned in_bytes;             // extent of that view (32-bit buffer offsets); 0 = too large
+    void* out;                     // bf16 NHWC view [B, H, W, c] with pixel stride ldo (another buffer than `in`)
+    int ldo;
+    int B, H, W, c, hidden;
+    const void* w12;               // cv1 | cv2 stacked: [c rows][kpad12], K = c
+    const void* wb1;               // bottleneck cv1: [hidden][kpadb1], K = hidden
+    const void* wb2;               // bottleneck cv2 (3x3): [hidden][kpadb2], K = (tap, hidden)
+    const void* w3;                // cv3: [c][kpad3], K = (bottleneck output | cv2 output)
+    const float *b12, *bb1, *bb2, *b3;
+    int kpad12, kpadb1, kpadb2, kpad3;
+    int shortcut;                  // the bottleneck adds its input (blocks.py:88-90)
+    unsigned opts;
+    int device, n_cu;
+};
+bool csp_stage_supported(const CspStageArgs& a);
+hipError_t launch_csp_stage(const CspStageArgs& a, hipStream_t s);
 
 // ---- layout / glue kernels (k_misc.hip) ----
 // boundary conversion: caller tensor (NCHW/NHWC, fp32/u8) -> engine NHWC T with C padded to Cpad (zeros);
