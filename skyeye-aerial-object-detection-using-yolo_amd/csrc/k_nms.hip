@@ -9,9 +9,9 @@
 //               key = ~monotone(score) << 32 | candidate index  => ascending key order is "score descending,
 //               lower index first", the tie rule fixed by this build
 //   4. sort     bitonic sort of the keys, per image, padded to a power of two; chunks of 16384 keys in LDS
-//   5. greedy   one wavefront per image walks the sorted candidates 64 at a time: each lane tests its box against
-//               the kept list (LDS), then the 64 lanes resolve among themselves in score order with ballots;
-//               stops at max_det kept or max_nms visited (metrics.py:434-435,443-444)
+//   5. greedy   one workgroup of 16 wavefronts per image walks the sorted candidates 1024 at a time: wave by wave the 64 lanes
+//               resolve among themselves in score order with ballots, the later waves test their boxes against the boxes that
+//               were just kept (LDS); stops at max_det kept or max_nms visited (metrics.py:434-435,443-444)
 //
 // This file is compiled with -ffp-contract=off: IoU and the class-offset arithmetic must round exactly like the
 // fp32 tensor ops of the reference so that the kept set is bit-identical to the oracle's.
@@ -235,11 +235,18 @@ __device__ __forceinline__ bool iou_gt(float kx1, float ky1, float kx2, float ky
     return iou > thr;
 }
 
-// one wavefront per image
-__global__ void __launch_bounds__(64) nms_greedy_kernel(const NmsArgs a)
+// One workgroup of GW wavefronts per image.  The sorted candidates are walked GW * 64 at a time, one per thread; inside such a
+// super-block wave w owns candidates [64 w, 64 w + 64).  In block order: the owning wave resolves its 64 lanes among themselves in
+// score order with ballots (appending to the kept list in LDS), a barrier publishes the new kept boxes, and every LATER wave tests
+// its own candidates against just those -- so the n x kept IoU tests of the greedy scan run GW waves wide while the order of
+// decisions (and with it the kept set) is exactly that of the sequential scan.  Stops at max_det kept or max_nms visited
+// (metrics.py:434-435,443-444).
+static constexpr int GW = 16;
+__global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
 {
-    extern __shared__ float kb[];   // [max_det][5]: x1, y1, x2, y2, area of kept boxes (class offset applied)
-    const int b = blockIdx.x, lane = threadIdx.x;
+    extern __shared__ float kb[];   // [max_det][5]: x1, y1, x2, y2, area of kept boxes (class offset applied); then int s_kept[2]
+    int* const s_kept = reinterpret_cast<int*>(kb + (size_t)a.max_det * 5);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int no = a.nc + 5;
     const int cols = (a.mode == 0 && a.nc > 1) ? 7 : 6;
     int n = a.totals[b];
@@ -248,8 +255,8 @@ __global__ void __launch_bounds__(64) nms_greedy_kernel(const NmsArgs a)
     int kept = 0;
     const unsigned long long* keys = a.keys + (long)b * a.cap;
     float* out = a.out + (long)b * a.max_det * 7;
-    for (int base = 0; base < n && kept < a.max_det; base += 64) {
-        const int k = base + lane;
+    for (int sb = 0; sb < n && kept < a.max_det; sb += GW * 64) {
+        const int k = sb + tid;
         bool alive = k < n;
         float b0 = 0, b1 = 0, b2 = 0, b3 = 0, score = 0, c5 = 0, c6 = 0;
         float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
@@ -267,34 +274,52 @@ __global__ void __launch_bounds__(64) nms_greedy_kernel(const NmsArgs a)
             x1 = b0 + c; y1 = b1 + c; x2 = b2 + c; y2 = b3 + c;
             area = (x2 - x1) * (y2 - y1);
         }
-        // against the boxes kept so far
+        // against the boxes kept in earlier super-blocks
         for (int t = 0; t < kept; ++t) {
             if (!__any(alive)) break;
             const float* q = kb + t * 5;
             if (alive && iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) alive = false;
         }
-        // among the 64 lanes, in score order
-        for (int i = 0; i < 64; ++i) {
-            const unsigned long long m = __ballot(alive);
-            if (!((m >> i) & 1ull)) continue;
-            if (kept >= a.max_det) break;
-            const float kx1 = __shfl(x1, i), ky1 = __shfl(y1, i), kx2 = __shfl(x2, i), ky2 = __shfl(y2, i), ka = __shfl(area, i);
-            if (lane == i) {
-                float* q = kb + kept * 5;
-                q[0] = x1; q[1] = y1; q[2] = x2; q[3] = y2; q[4] = area;
-                float* o = out + (long)kept * 7;
-                o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = score; o[5] = c5;
-                o[6] = cols == 7 ? c6 : 0.0f;
+        for (int blk = 0; blk < GW; ++blk) {
+            if (sb + blk * 64 >= n) break;                       // (uniform)
+            const int kept0 = kept;
+            if (wave == blk) {
+                // among the 64 lanes, in score order
+                int kk = kept;
+                for (int i = 0; i < 64; ++i) {
+                    const unsigned long long m = __ballot(alive);
+                    if (!((m >> i) & 1ull)) continue;
+                    if (kk >= a.max_det) break;
+                    const float kx1 = __shfl(x1, i), ky1 = __shfl(y1, i), kx2 = __shfl(x2, i), ky2 = __shfl(y2, i), ka = __shfl(area, i);
+                    if (lane == i) {
+                        float* q = kb + kk * 5;
+                        q[0] = x1; q[1] = y1; q[2] = x2; q[3] = y2; q[4] = area;
+                        float* o = out + (long)kk * 7;
+                        o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = score; o[5] = c5;
+                        o[6] = cols == 7 ? c6 : 0.0f;
+                    }
+                    ++kk;
+                    if (lane > i && alive && iou_gt(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, a.iou)) alive = false;
+                }
+                if (lane == 0) s_kept[blk & 1] = kk;
             }
-            ++kept;
-            if (lane > i && alive && iou_gt(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, a.iou)) alive = false;
+            __syncthreads();                                     // the kept list up to s_kept is published
+            kept = s_kept[blk & 1];                              // (slot blk & 1 is next written two barriers from here)
+            if (kept >= a.max_det) break;                        // (uniform)
+            if (wave > blk) {
+                for (int t = kept0; t < kept; ++t) {
+                    if (!__any(alive)) break;
+                    const float* q = kb + t * 5;
+                    if (alive && iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) alive = false;
+                }
+            }
         }
-        __syncthreads();   // single wave: orders the LDS writes of kb before the next block's reads
+        __syncthreads();   // the s_kept slots and the waves' roles start over
     }
-    if (lane == 0) a.counts[b] = kept;
+    if (tid == 0) a.counts[b] = kept;
     // rows past the kept ones are defined (zeros): callers hand over uninitialised buffers and the fixed-capacity block
     // that travels through the RCCL all-gather is the same bytes on every run
-    for (int i = kept * 7 + lane; i < a.max_det * 7; i += 64) out[i] = 0.0f;
+    for (int i = kept * 7 + tid; i < a.max_det * 7; i += GW * 64) out[i] = 0.0f;
 }
 
 static long next_pow2(long v)
@@ -336,7 +361,7 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
             hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)((a.cap / 2 + 255) / 256), a.B), dim3(256), 0, s, a, k, j);
         hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 0, k);
     }
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(64), (size_t)a.max_det * 5 * sizeof(float), s, a);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(GW * 64), (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int), s, a);
     return hipGetLastError();
 }
 
