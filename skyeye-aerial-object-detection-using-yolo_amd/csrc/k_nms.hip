@@ -9,7 +9,7 @@
 //               key = ~monotone(score) << 32 | candidate index  => ascending key order is "score descending,
 //               lower index first", the tie rule fixed by this build
 //   4. sort     bitonic sort of the keys, per image, padded to a power of two; chunks of 16384 keys in LDS
-//   5. greedy   one workgroup of 16 wavefronts per image walks the sorted candidates 1024 at a time: wave by wave the 64 lanes
+//   5. greedy   one workgroup of 8 wavefronts per image walks the sorted candidates 512 at a time: wave by wave the 64 lanes
 //               resolve among themselves in score order with ballots, the later waves test their boxes against the boxes that
 //               were just kept (LDS); stops at max_det kept or max_nms visited (metrics.py:434-435,443-444)
 //
@@ -235,17 +235,28 @@ __device__ __forceinline__ bool iou_gt(float kx1, float ky1, float kx2, float ky
     return iou > thr;
 }
 
+// Filter in front of iou_gt: boxes that do not overlap in both axes have inter = 0 and are never suppressed (0 / union > thr is false
+// for every union, NaN included, as long as thr >= 0) -- most pairs, since the class offset moves the classes apart.  Same
+// subtractions as iou_gt, so the filter passes exactly the pairs whose w and h are positive there.
+__device__ __forceinline__ bool boxes_overlap(float kx1, float ky1, float kx2, float ky2, float x1, float y1, float x2, float y2)
+{
+    const float w = fminf(kx2, x2) - fmaxf(kx1, x1);
+    const float h = fminf(ky2, y2) - fmaxf(ky1, y1);
+    return w > 0.0f && h > 0.0f;
+}
+
 // One workgroup of GW wavefronts per image.  The sorted candidates are walked GW * 64 at a time, one per thread; inside such a
 // super-block wave w owns candidates [64 w, 64 w + 64).  In block order: the owning wave resolves its 64 lanes among themselves in
 // score order with ballots (appending to the kept list in LDS), a barrier publishes the new kept boxes, and every LATER wave tests
 // its own candidates against just those -- so the n x kept IoU tests of the greedy scan run GW waves wide while the order of
 // decisions (and with it the kept set) is exactly that of the sequential scan.  Stops at max_det kept or max_nms visited
 // (metrics.py:434-435,443-444).
-static constexpr int GW = 16;
+static constexpr int GW = 8;
 __global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
 {
     extern __shared__ float kb[];   // [max_det][5]: x1, y1, x2, y2, area of kept boxes (class offset applied); then int s_kept[2]
     int* const s_kept = reinterpret_cast<int*>(kb + (size_t)a.max_det * 5);
+    float* const kbb = reinterpret_cast<float*>(s_kept + 2);      // [64][5]: the boxes of the block being resolved
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int no = a.nc + 5;
     const int cols = (a.mode == 0 && a.nc > 1) ? 7 : 6;
@@ -253,6 +264,7 @@ __global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
     if (n > a.max_nms) n = a.max_nms;
     if ((long)n > a.cap) n = (int)a.cap;
     int kept = 0;
+    const bool nofilter = !(a.iou >= 0.0f);          // a negative threshold suppresses disjoint boxes too: no overlap filter
     const unsigned long long* keys = a.keys + (long)b * a.cap;
     float* out = a.out + (long)b * a.max_det * 7;
     for (int sb = 0; sb < n && kept < a.max_det; sb += GW * 64) {
@@ -274,45 +286,78 @@ __global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
             x1 = b0 + c; y1 = b1 + c; x2 = b2 + c; y2 = b3 + c;
             area = (x2 - x1) * (y2 - y1);
         }
+        // This thread's box against up to 64 boxes in LDS ([cnt][5]): the boxes among `allowed` that suppress it.  Pass 1 marks the
+        // overlapping ones (branch-free, the LDS reads pipeline), pass 2 takes the IoU decision for the marked ones only (per-lane
+        // lists, a handful of entries).
+        auto suppressors = [&](const float* boxes, int cnt, unsigned long long allowed) -> unsigned long long {
+            unsigned long long mask = 0ull;
+            if (nofilter) mask = cnt == 64 ? ~0ull : (1ull << cnt) - 1ull;
+            else {
+#pragma unroll 4
+                for (int t = 0; t < cnt; ++t) {
+                    const float* q = boxes + t * 5;
+                    mask |= (unsigned long long)boxes_overlap(q[0], q[1], q[2], q[3], x1, y1, x2, y2) << t;
+                }
+            }
+            mask &= allowed;
+            unsigned long long hits = 0ull;
+            while (__any(mask != 0ull)) {
+                if (mask) {
+                    const int t = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1ull;
+                    const float* q = boxes + t * 5;
+                    if (iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) hits |= 1ull << t;
+                }
+            }
+            return hits;
+        };
+        auto test_kept = [&](int t0, int t1) {
+            for (int tb = t0; tb < t1; tb += 64)
+                if (suppressors(kb + tb * 5, tb + 64 < t1 ? 64 : t1 - tb, alive ? ~0ull : 0ull)) alive = false;
+        };
         // against the boxes kept in earlier super-blocks
-        for (int t = 0; t < kept; ++t) {
-            if (!__any(alive)) break;
-            const float* q = kb + t * 5;
-            if (alive && iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) alive = false;
-        }
+        if (kept > 0 && __any(alive)) test_kept(0, kept);
         for (int blk = 0; blk < GW; ++blk) {
             if (sb + blk * 64 >= n) break;                       // (uniform)
             const int kept0 = kept;
             if (wave == blk) {
-                // among the 64 lanes, in score order
-                int kk = kept;
-                for (int i = 0; i < 64; ++i) {
-                    const unsigned long long m = __ballot(alive);
-                    if (!((m >> i) & 1ull)) continue;
-                    if (kk >= a.max_det) break;
-                    const float kx1 = __shfl(x1, i), ky1 = __shfl(y1, i), kx2 = __shfl(x2, i), ky2 = __shfl(y2, i), ka = __shfl(area, i);
-                    if (lane == i) {
-                        float* q = kb + kk * 5;
-                        q[0] = x1; q[1] = y1; q[2] = x2; q[3] = y2; q[4] = area;
-                        float* o = out + (long)kk * 7;
-                        o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = score; o[5] = c5;
-                        o[6] = cols == 7 ? c6 : 0.0f;
-                    }
-                    ++kk;
-                    if (lane > i && alive && iou_gt(kx1, ky1, kx2, ky2, ka, x1, y1, x2, y2, area, a.iou)) alive = false;
+                // Among the 64 lanes, in score order, without a serial walk: (1) every lane collects `sup`, the earlier alive lanes whose
+                // box suppresses its own (the block's boxes go through an LDS scratch, then the same two passes as against the kept
+                // list); (2) the kept set K is the unique set with
+                // "lane j is in K <=> alive and no lane of sup_j is in K".  Iterating K <- {j alive : sup_j & K == 0} from K = all alive
+                // settles lane 0 first, then every lane whose earlier lanes are settled: it reaches that set (in practice in 2-3 rounds).
+                const unsigned long long A = __ballot(alive);
+                {
+                    float* q = kbb + lane * 5;
+                    q[0] = x1; q[1] = y1; q[2] = x2; q[3] = y2; q[4] = area;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // (one wave writes and reads kbb: no barrier)
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long sup = suppressors(kbb, 64, alive ? A & ((1ull << lane) - 1ull) : 0ull);
+                unsigned long long K = A, prev;
+                do {
+                    prev = K;
+                    K = __ballot(alive && (sup & prev) == 0ull);
+                } while (K != prev);
+                // at most max_det boxes in all: the first (max_det - kept) lanes of K
+                const int rank = __popcll(K & ((1ull << lane) - 1ull)), avail = a.max_det - kept;
+                const bool mine = ((K >> lane) & 1ull) != 0ull && rank < avail;
+                const int my = mine ? kept + rank : -1;
+                const int nk = __popcll(K);
+                const int kk = kept + (nk < avail ? nk : avail);
+                if (my >= 0) {
+                    float* q = kb + my * 5;
+                    q[0] = x1; q[1] = y1; q[2] = x2; q[3] = y2; q[4] = area;
+                    float* o = out + (long)my * 7;
+                    o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = score; o[5] = c5;
+                    o[6] = cols == 7 ? c6 : 0.0f;
                 }
                 if (lane == 0) s_kept[blk & 1] = kk;
             }
             __syncthreads();                                     // the kept list up to s_kept is published
             kept = s_kept[blk & 1];                              // (slot blk & 1 is next written two barriers from here)
             if (kept >= a.max_det) break;                        // (uniform)
-            if (wave > blk) {
-                for (int t = kept0; t < kept; ++t) {
-                    if (!__any(alive)) break;
-                    const float* q = kb + t * 5;
-                    if (alive && iou_gt(q[0], q[1], q[2], q[3], q[4], x1, y1, x2, y2, area, a.iou)) alive = false;
-                }
-            }
+            if (wave > blk && __any(alive)) test_kept(kept0, kept);
         }
         __syncthreads();   // the s_kept slots and the waves' roles start over
     }
@@ -361,7 +406,7 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
             hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)((a.cap / 2 + 255) / 256), a.B), dim3(256), 0, s, a, k, j);
         hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 0, k);
     }
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(GW * 64), (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int), s, a);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(GW * 64), (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int) + 64 * 5 * sizeof(float), s, a);
     return hipGetLastError();
 }
 
