@@ -19,6 +19,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 namespace sky {
 
 static constexpr int ROWS = 256;        // rows per count/emit block
@@ -171,8 +173,8 @@ __global__ void __launch_bounds__(256) nms_pad_kernel(const NmsArgs a)
     const int b = blockIdx.y;
     const int total = a.totals[b];
     const long P = padded_len(total);
-    const long k = (long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= total && k < P && k < a.cap) a.keys[(long)b * a.cap + k] = ~0ull;
+    const long end = P < a.cap ? P : a.cap;
+    for (long k = total + (long)blockIdx.x * 256 + threadIdx.x; k < end; k += (long)gridDim.x * 256) a.keys[(long)b * a.cap + k] = ~0ull;
 }
 
 // bitonic sort inside LDS.  full = 1: sort the chunk from k = 2; full = 0: only the merge tail (j = CHUNK/2 .. 1)
@@ -190,13 +192,16 @@ __global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a, i
     __syncthreads();
     const long k0 = full ? 2 : kstage;
     const long k1 = full ? len : kstage;
+    const int half = (int)(len >> 1);
     for (long k = k0; k <= k1; k <<= 1) {
         long jstart = k >> 1;
-        if (jstart > len / 2) jstart = len / 2;
-        for (long j = jstart; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < len / 2; t += SORT_T) {
-                const int lo = (int)(((t / j) * 2 * j) + (t % j));
-                const int hi = lo + (int)j;
+        if (jstart > half) jstart = half;
+        // j is a power of two: pair index t -> lo = (t / j) * 2j + t % j with shifts (the 64-bit divisions of the plain form cost more
+        // than the compare-exchange); direction from bit k of the element's global index
+        for (int j = (int)jstart, sh = 31 - __builtin_clz((unsigned)jstart); j > 0; j >>= 1, --sh) {
+            for (int t = threadIdx.x; t < half; t += SORT_T) {
+                const int lo = ((t >> sh) << (sh + 1)) | (t & (j - 1));
+                const int hi = lo + j;
                 const bool asc = (((base + lo) & k) == 0);
                 const unsigned long long x = sk[lo], y = sk[hi];
                 if ((x > y) == asc) { sk[lo] = y; sk[hi] = x; }
@@ -213,14 +218,15 @@ __global__ void __launch_bounds__(256) nms_sort_global_kernel(const NmsArgs a, l
     const int b = blockIdx.y;
     const long P = padded_len(a.totals[b]);
     if (k > P) return;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= P / 2) return;
-    const long lo = (t / j) * 2 * j + (t % j);
-    const long hi = lo + j;
+    const int sh = 63 - __builtin_clzll((unsigned long long)j);
     unsigned long long* g = a.keys + (long)b * a.cap;
-    const bool asc = ((lo & k) == 0);
-    const unsigned long long x = g[lo], y = g[hi];
-    if ((x > y) == asc) { g[lo] = y; g[hi] = x; }
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < P / 2; t += (long)gridDim.x * 256) {
+        const long lo = ((t >> sh) << (sh + 1)) | (t & (j - 1));
+        const long hi = lo + j;
+        const bool asc = ((lo & k) == 0);
+        const unsigned long long x = g[lo], y = g[hi];
+        if ((x > y) == asc) { g[lo] = y; g[hi] = x; }
+    }
 }
 
 __device__ __forceinline__ bool iou_gt(float kx1, float ky1, float kx2, float ky2, float karea, float x1, float y1, float x2,
@@ -393,7 +399,7 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
     hipLaunchKernelGGL(nms_count_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(a.B), dim3(256), 0, s, a, nblk);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
-    hipLaunchKernelGGL(nms_pad_kernel, dim3((unsigned)((a.cap + 255) / 256), a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nms_pad_kernel, dim3((unsigned)std::min<long>((a.cap + 255) / 256, 16), a.B), dim3(256), 0, s, a);
     const unsigned chunks = (unsigned)((a.cap + CHUNK - 1) / CHUNK);
     static size_t attr[16] = {0};
     {
@@ -403,7 +409,7 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
     hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 1, 0L);
     for (long k = 2L * CHUNK; k <= a.cap; k <<= 1) {
         for (long j = k >> 1; j >= CHUNK; j >>= 1)
-            hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)((a.cap / 2 + 255) / 256), a.B), dim3(256), 0, s, a, k, j);
+            hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)std::min<long>((a.cap / 2 + 255) / 256, 64), a.B), dim3(256), 0, s, a, k, j);
         hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 0, k);
     }
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(GW * 64), (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int) + 64 * 5 * sizeof(float), s, a);
