@@ -463,6 +463,10 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
     if (fused) *fused = 0;
+    if (a.head && !(a.opts & OPT_NO_STREAM)) {
+        const hipError_t e = launch_head_stream(dtype, a, s, variant);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (!(a.opts & OPT_NO_STREAM)) {   // A/B switch for profiling
         const hipError_t eh = launch_conv_halo(dtype, a, s, variant, fused);
         if (eh != hipErrorNotSupported) return eh;

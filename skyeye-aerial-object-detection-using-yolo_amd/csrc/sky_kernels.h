@@ -33,6 +33,8 @@ enum PlanOpt : unsigned {
     OPT_NO_STEM_DOWN = 1u << 13,     // SKY_NO_STEM_DOWN     stem and first stride-2 convolution as two launches (default: one kernel where covered)
     OPT_NO_WINATTN = 1u << 14,       // SKY_NO_WINATTN       8 x 8 windows on the general flash kernel (default: the one-wave-per-(window, head) kernel)
     OPT_NO_CSP_STAGE = 1u << 15,     // SKY_NO_CSP_STAGE     the first CSP stage as four launches (default: one kernel where covered)
+    OPT_NO_HEAD_STREAM = 1u << 21,   // SKY_NO_HEAD_STREAM   detection levels on the implicit-GEMM tile kernel (default: the streaming head kernel)
+    OPT_HEAD_STREAM_FORCE = 1u << 22,// SKY_HEAD_STREAM=force the streaming head kernel on small levels too (default: only where 32-pixel steps fill the device)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -173,6 +175,10 @@ struct CspStageArgs {
     unsigned opts;
     int device, n_cu;
 };
+// detection level (1x1 + bias + decode) as a byte streamer, bf16 (k_head.hip); hipErrorNotSupported: take the tile kernel
+bool head_stream_supported(int dtype, const ConvArgs& a);
+hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant);
+
 bool csp_stage_supported(const CspStageArgs& a);
 hipError_t launch_csp_stage(const CspStageArgs& a, hipStream_t s);
 
