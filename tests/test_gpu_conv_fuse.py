@@ -60,10 +60,12 @@ def test_fused_pointwise_matches_oracle_and_unfused(case, prec):
         yf = mf(xg).cpu().numpy()
         tags_f = _tags(mf, xg)
         mu = _build(c, n, prec, False)
+        os.environ["SKY_NO_CSP_STAGE"] = "1"      # the layer-by-layer graph (by default the 64-channel n = 1 block is ONE kernel, k_csp_stage.hip)
         yu = mu(xg).cpu().numpy()
         tags_u = _tags(mu, xg)
     finally:
         os.environ.pop("SKY_FUSE", None)
+        os.environ.pop("SKY_NO_CSP_STAGE", None)
     # hidden 64: every bottleneck's cv1 is fused (into cv1|cv2, then into the previous 3x3); hidden 32: only the first one
     # (the narrow-input 3x3 kernel has no fused form and the engine falls back to the separate launch)
     want = n if c == 128 else 1
