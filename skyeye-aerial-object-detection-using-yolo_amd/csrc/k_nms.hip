@@ -412,7 +412,13 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
             hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)std::min<long>((a.cap / 2 + 255) / 256, 64), a.B), dim3(256), 0, s, a, k, j);
         hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 0, k);
     }
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(GW * 64), (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int) + 64 * 5 * sizeof(float), s, a);
+    const size_t glds = (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int) + 64 * 5 * sizeof(float);
+    if (glds > 48 * 1024) {         // max_detections above ~2400: the kept list needs more than the default dynamic LDS limit
+        static size_t gattr[16] = {0};
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(nms_greedy_kernel), glds, a.device, gattr);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(a.B), dim3(GW * 64), glds, s, a);
     return hipGetLastError();
 }
 

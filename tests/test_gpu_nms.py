@@ -56,3 +56,40 @@ def test_nms_full_size_sorted_and_idempotent():
         a = a.cpu().numpy()
         assert np.all(np.diff(a[:, 4]) <= 0), "kept rows must be in descending score order"
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _crowded(nc, batch, n, seed, clusters=40):
+    """Rows whose boxes pile up on a few centres: most candidates are suppressed, so the greedy scan visits thousands of candidates
+    (many 512-candidate steps of the workgroup kernel) before it has kept max_detections boxes."""
+    r = np.random.default_rng(seed)
+    pred = np.zeros((batch, n, nc + 5), np.float32)
+    for b in range(batch):
+        cx = r.uniform(100, 1100, clusters)
+        cy = r.uniform(100, 1100, clusters)
+        k = r.integers(0, clusters, n)
+        pred[b, :, 0] = cx[k] + r.normal(0, 6, n)
+        pred[b, :, 1] = cy[k] + r.normal(0, 6, n)
+        pred[b, :, 2] = r.uniform(60, 90, n)
+        pred[b, :, 3] = r.uniform(60, 90, n)
+        pred[b, :, 4] = r.permutation(n).astype(np.float32) / n * 0.7 + 0.3        # distinct objectness
+        pred[b, :, 5:] = r.uniform(0.5, 1.0, (n, nc))
+    return pred
+
+
+@pytest.mark.parametrize("mode", ["literal", "corrected"])
+@pytest.mark.parametrize("max_det", [1, 17, 300, 4096])
+def test_nms_crowded_scenes_and_kept_list_sizes_match_oracle(mode, max_det):
+    pred = _crowded(3, 2, 6000, 11)
+    kw = dict(conf_threshold=0.3, iou_threshold=0.45, max_detections=max_det)
+    ref = O.non_max_suppression(pred, mode=mode, **kw)
+    res = non_max_suppression(torch.from_numpy(pred).cuda(), mode=mode, **kw)
+    for a, b in zip(res, ref):
+        assert a.shape[0] == b.shape[0] and a.shape[0] <= max_det
+        if b.shape[0]:
+            assert np.array_equal(a.cpu().numpy().view(np.uint32), b.view(np.uint32))
+
+
+def test_nms_without_candidates_returns_empty_rows():
+    pred = make_predictions(4, 3, 2000, 5)
+    res = non_max_suppression(torch.from_numpy(pred).cuda(), conf_threshold=2.0, iou_threshold=0.5)       # nothing passes
+    assert [int(r.shape[0]) for r in res] == [0, 0, 0]
