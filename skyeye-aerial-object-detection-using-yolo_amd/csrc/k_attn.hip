@@ -199,11 +199,12 @@ __global__ void __launch_bounds__(64) attention_kernel(const T* __restrict__ qkv
 //     n = lane & 15, the keys 4g..4g+3 of each 16-key tile: the softmax reductions over keys are in-lane plus two
 //     cross-lane-group steps, and the running maximum / sum / rescale factor of a query live in the lanes that own it;
 //   * O^T = V^T P^T: the B operand of K-step ks (32 keys) is lane (n, g)'s OWN eight probabilities of tiles 2ks, 2ks+1
-//     packed to bf16 -- no data movement --, provided V^T is staged in LDS with the matching key order
-//     slot(key) = ks*32 + g*8 + t*4 + j for key = (2ks + t)*16 + 4g + j;
+//     packed to bf16 -- no data movement --; the matching A operand (channel row, the lane's own 8 keys) comes out of the row-major
+//     V tile through ds_read_b64_tr_b16 (4 keys x 16 channels per 16-lane group): V is staged with 16-byte writes;
 //   * O^T's D layout gives lane (n, g) the channels e = 16*tile + 4g..4g+3 of its query: 8-byte stores.
 // Online softmax in fp32 (exp on v_exp_f32); P and V enter the second product as bf16.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_att_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_att_t;
 
 // WIN: the groups are ws x ws windows of a [B, mh, mw] map addressed in place (token_row) and the relative position bias
 // [heads, N, N] (+ optional mask [nW, N, N]) is added to the scaled scores (WindowedSelfAttention, attention.py:377-392).
@@ -217,9 +218,17 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
     constexpr int KROW = D * 2;                 // bytes of one K row in LDS
     constexpr int CM = (D / 8 < 8 ? D / 8 : 8) - 1;   // chunk-swizzle mask inside one K row (rows of 32 channels have 4 chunks)
     __shared__ __attribute__((aligned(16))) char kl[64 * KROW];       // K tile [64 keys][D], chunks swizzled by (key >> 1) & 7
-    __shared__ __attribute__((aligned(16))) char vl[D * 128];         // V^T tile [D channels][64 key slots], same swizzle by channel
+    __shared__ __attribute__((aligned(16))) char vl[64 * KROW];       // V tile [64 keys][D], row-major; 32-byte channel pairs swizzled by the key
+                                                                      // so that the transposed reads below are conflict-free
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
+    // byte offset of 16-byte chunk c of key row `key` in the V tile: the 32-byte pair index is XORed with a function of the key such
+    // that the 8 key rows a 32-lane half reads in one transposed read fall on 8 distinct groups of 8 banks ((key * D/16 + pair) mod 8)
+    auto vchunk = [](int c, int key) -> int {
+        constexpr int PP = D / 16;                                     // pairs per row: 2, 4, 8
+        const int f = PP == 2 ? (key >> 2) & 1 : PP == 4 ? (key >> 1) & 3 : key & 7;
+        return ((((c >> 1) ^ f) << 1) | (c & 1)) << 4;
+    };
     const int h = blockIdx.y, b = blockIdx.z;                          // b: image, or window when WIN
     const int q = blockIdx.x * 64 + wave * 16 + n;                     // this lane's query
     const bool qok = q < N;
@@ -249,15 +258,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
                 vv = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + 2 * C + h * D + c * 8);
             }
             *reinterpret_cast<u32x4_t*>(kl + key * KROW + (((c & ~CM) | ((c ^ (key >> 1)) & CM)) << 4)) = kv;
-            const int T = key >> 4, r16 = key & 15;
-            const int slot = (T >> 1) * 32 + (r16 >> 2) * 8 + (T & 1) * 4 + (r16 & 3);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = c * 8 + e;
-                const unsigned short val = (unsigned short)(vv[e >> 1] >> ((e & 1) * 16));
-                const int chunk = slot >> 3;                           // 16-byte chunk of the V^T row, swizzled by the channel
-                *reinterpret_cast<unsigned short*>(vl + ch * 128 + (((chunk ^ (ch >> 1)) & 7) << 4) + (slot & 7) * 2) = val;
-            }
+            *reinterpret_cast<u32x4_t*>(vl + key * KROW + vchunk(c, key)) = vv;
         }
         __syncthreads();
         // ---- S^T tiles: keys 16T + 4g + r of this 64-key block x query n ----
@@ -319,9 +320,18 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
             }
 #pragma unroll
             for (int t = 0; t < OT; ++t) {
-                const int ch = t * 16 + n;                             // A operand row: channel
-                const int chunk = ks * 4 + g;
-                const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(vl + ch * 128 + (((chunk ^ (ch >> 1)) & 7) << 4));
+                // A operand (channel t*16 + n, the 8 keys of this lane's K-group): two transposed reads of 4 keys x 16 channels.  Lane
+                // 4q + p of a 16-lane group supplies key row q, channels 4p .. 4p+3 of the block; lane i receives channel i.
+                u32x4_t vf;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int krow = (2 * ks + e) * 16 + 4 * g + (n >> 2);
+                    const char* ap = vl + krow * KROW + vchunk(t * 2 + ((n & 3) >> 1), krow) + 8 * (n & 1);
+                    const s16x4_att_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_att_t*)ap);
+                    const uint2 u = __builtin_bit_cast(uint2, r);
+                    vf[2 * e] = u.x;
+                    vf[2 * e + 1] = u.y;
+                }
                 o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, vf), __builtin_bit_cast(bf16x8_att_t, pf), o[t], 0, 0, 0);
             }
         }
@@ -351,8 +361,6 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
 // The four waves of a workgroup take four neighbouring heads of the same windows, so their 64-byte head slices share
 // cache lines.  Arithmetic and its order are those of attention_mfma_kernel<32, true> with one key block: results are
 // bit-identical (tests/test_gpu_attention_mfma.py).
-typedef __attribute__((ext_vector_type(4))) short s16x4_att_t;
-
 __global__ void __launch_bounds__(256) window_attention_kernel(const __bf16* __restrict__ qkv, int ldq, __bf16* __restrict__ out, int ldo, int G,
                                                                int C, float scale, const float* __restrict__ bias, int ws, int mh, int mw)
 {
