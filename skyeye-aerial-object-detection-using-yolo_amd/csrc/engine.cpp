@@ -2182,6 +2182,7 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
         a.blk_counts = (int*)w; w += ((size_t)B * nblk * sizeof(int) + 255) / 256 * 256;
         a.totals = (int*)w; w += ((size_t)B * sizeof(int) + 255) / 256 * 256;
         a.keys = (unsigned long long*)w; w += (size_t)B * cap * sizeof(unsigned long long);
+        a.keys2 = (unsigned long long*)w; w += (size_t)B * cap * sizeof(unsigned long long);
         a.cand = (float*)w;
         SKY_HIP(launch_nms(a, (hipStream_t)stream));
     });

@@ -8,7 +8,8 @@
 //   3. emit     candidate records in (row, class) order + 64-bit sort keys
 //               key = ~monotone(score) << 32 | candidate index  => ascending key order is "score descending,
 //               lower index first", the tie rule fixed by this build
-//   4. sort     bitonic sort of the keys, per image, padded to a power of two; chunks of 16384 keys in LDS
+//   4. sort     per image, padded to a power of two: bitonic sort of chunks of 16384 keys in LDS, then merge levels (merge path,
+//               16384 -> 32768 -> ...) between two key buffers; an image with at most 16384 candidates takes none of them
 //   5. greedy   one workgroup of 8 wavefronts per image walks the sorted candidates 512 at a time: wave by wave the 64 lanes
 //               resolve among themselves in score order with ballots, the later waves test their boxes against the boxes that
 //               were just kept (LDS); stops at max_det kept or max_nms visited (metrics.py:434-435,443-444)
@@ -177,32 +178,28 @@ __global__ void __launch_bounds__(256) nms_pad_kernel(const NmsArgs a)
     for (long k = total + (long)blockIdx.x * 256 + threadIdx.x; k < end; k += (long)gridDim.x * 256) a.keys[(long)b * a.cap + k] = ~0ull;
 }
 
-// bitonic sort inside LDS.  full = 1: sort the chunk from k = 2; full = 0: only the merge tail (j = CHUNK/2 .. 1)
-// of global stage `kstage`.
-__global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a, int full, long kstage)
+// Bitonic sort of one chunk of CHUNK keys inside LDS, ascending (the direction of a compare-exchange comes from the element's index
+// INSIDE the chunk, so every chunk ends ascending: the merge levels below want sorted runs, not a bitonic sequence).
+__global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a)
 {
     const int b = blockIdx.y;
     const long P = padded_len(a.totals[b]);
     const long base = (long)blockIdx.x * CHUNK;
-    if (base >= P || (!full && kstage > P)) return;
+    if (base >= P) return;
     const long len = P < CHUNK ? P : CHUNK;
     extern __shared__ unsigned long long sk[];   // CHUNK keys
     unsigned long long* g = a.keys + (long)b * a.cap + base;
     for (int i = threadIdx.x; i < len; i += SORT_T) sk[i] = g[i];
     __syncthreads();
-    const long k0 = full ? 2 : kstage;
-    const long k1 = full ? len : kstage;
     const int half = (int)(len >> 1);
-    for (long k = k0; k <= k1; k <<= 1) {
-        long jstart = k >> 1;
-        if (jstart > half) jstart = half;
+    for (long k = 2; k <= len; k <<= 1) {
         // j is a power of two: pair index t -> lo = (t / j) * 2j + t % j with shifts (the 64-bit divisions of the plain form cost more
-        // than the compare-exchange); direction from bit k of the element's global index
-        for (int j = (int)jstart, sh = 31 - __builtin_clz((unsigned)jstart); j > 0; j >>= 1, --sh) {
+        // than the compare-exchange)
+        for (int j = (int)(k >> 1), sh = 31 - __builtin_clz((unsigned)(k >> 1)); j > 0; j >>= 1, --sh) {
             for (int t = threadIdx.x; t < half; t += SORT_T) {
                 const int lo = ((t >> sh) << (sh + 1)) | (t & (j - 1));
                 const int hi = lo + j;
-                const bool asc = (((base + lo) & k) == 0);
+                const bool asc = ((lo & k) == 0);
                 const unsigned long long x = sk[lo], y = sk[hi];
                 if ((x > y) == asc) { sk[lo] = y; sk[hi] = x; }
             }
@@ -212,21 +209,64 @@ __global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a, i
     for (int i = threadIdx.x; i < len; i += SORT_T) g[i] = sk[i];
 }
 
-// one global compare-exchange step (j >= CHUNK) of stage k
-__global__ void __launch_bounds__(256) nms_sort_global_kernel(const NmsArgs a, long k, long j)
+// Merge level: sorted runs of R keys -> sorted runs of 2R keys, from `src` into `dst` (the two key buffers alternate level by level;
+// an image whose padded length P is at most R is finished and is left where it is: nms_sorted_keys() tells the reader where).  A
+// workgroup produces MSEG * 256 consecutive output keys of one pair of runs: two binary searches along the segment's first and last
+// diagonal (merge path: i keys of run A and d - i of run B lie below the cut; on ties B goes first) bound the pieces of A and B it
+// needs, those go to LDS with coalesced loads, and every thread cuts its own MSEG keys out of the LDS pieces the same way.
+static constexpr int MSEG = 8, MWG = MSEG * 256;
+__device__ __forceinline__ long merge_cut(const unsigned long long* A, long na, const unsigned long long* Bk, long nb, long d)
 {
-    const int b = blockIdx.y;
-    const long P = padded_len(a.totals[b]);
-    if (k > P) return;
-    const int sh = 63 - __builtin_clzll((unsigned long long)j);
-    unsigned long long* g = a.keys + (long)b * a.cap;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < P / 2; t += (long)gridDim.x * 256) {
-        const long lo = ((t >> sh) << (sh + 1)) | (t & (j - 1));
-        const long hi = lo + j;
-        const bool asc = ((lo & k) == 0);
-        const unsigned long long x = g[lo], y = g[hi];
-        if ((x > y) == asc) { g[lo] = y; g[hi] = x; }
+    long lo = d > nb ? d - nb : 0, hi = d < na ? d : na;            // i in [lo, hi]: keys taken from A among the first d
+    while (lo < hi) {
+        const long i = (lo + hi) >> 1;                              // A[i] against B[d - i - 1]
+        if (A[i] < Bk[d - i - 1]) lo = i + 1; else hi = i;
     }
+    return lo;
+}
+__global__ void __launch_bounds__(256) nms_merge_kernel(const NmsArgs a, long R, int level)
+{
+    __shared__ unsigned long long sa[MWG], sb[MWG];
+    __shared__ long cut[2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long P = padded_len(a.totals[b]);
+    if (P <= R) return;
+    const unsigned long long* src = ((level & 1) ? a.keys : a.keys2) + (long)b * a.cap;
+    unsigned long long* dst = ((level & 1) ? a.keys2 : a.keys) + (long)b * a.cap;
+    for (long o0 = (long)blockIdx.x * MWG; o0 < P; o0 += (long)gridDim.x * MWG) {
+        const long pair = o0 / (2 * R), d0 = o0 - pair * 2 * R;     // output keys [d0, d0 + MWG) of this pair of runs
+        const unsigned long long* A = src + pair * 2 * R;
+        const unsigned long long* Bk = A + R;
+        if (tid < 2) cut[tid] = merge_cut(A, R, Bk, R, d0 + tid * MWG);
+        __syncthreads();
+        const long ia0 = cut[0], ia1 = cut[1], ib0 = d0 - ia0, ib1 = d0 + MWG - ia1;
+        const int na = (int)(ia1 - ia0), nb = (int)(ib1 - ib0);     // na + nb = MWG
+        for (int i = tid; i < na; i += 256) sa[i] = A[ia0 + i];
+        for (int i = tid; i < nb; i += 256) sb[i] = Bk[ib0 + i];
+        __syncthreads();
+        const int d = tid * MSEG;
+        int i = (int)merge_cut(sa, na, sb, nb, d), j = d - i;
+        unsigned long long outv[MSEG];
+#pragma unroll
+        for (int e = 0; e < MSEG; ++e) {
+            const bool ta = j >= nb || (i < na && sa[i] < sb[j]);
+            outv[e] = ta ? sa[i] : sb[j];
+            i += ta ? 1 : 0;
+            j += ta ? 0 : 1;
+        }
+#pragma unroll
+        for (int e = 0; e < MSEG; ++e) dst[o0 + d + e] = outv[e];
+        __syncthreads();                                            // the LDS pieces are rewritten by the next segment
+    }
+}
+
+// where the sorted keys of image b ended up: every merge level an image takes flips the buffer
+__device__ __forceinline__ const unsigned long long* nms_sorted_keys(const NmsArgs& a, int b)
+{
+    const long P = padded_len(a.totals[b]);
+    int levels = 0;
+    for (long R = CHUNK; R < P; R <<= 1) ++levels;
+    return ((levels & 1) ? a.keys2 : a.keys) + (long)b * a.cap;
 }
 
 __device__ __forceinline__ bool iou_gt(float kx1, float ky1, float kx2, float ky2, float karea, float x1, float y1, float x2,
@@ -271,7 +311,7 @@ __global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
     if ((long)n > a.cap) n = (int)a.cap;
     int kept = 0;
     const bool nofilter = !(a.iou >= 0.0f);          // a negative threshold suppresses disjoint boxes too: no overlap filter
-    const unsigned long long* keys = a.keys + (long)b * a.cap;
+    const unsigned long long* keys = nms_sorted_keys(a, b);
     float* out = a.out + (long)b * a.max_det * 7;
     for (int sb = 0; sb < n && kept < a.max_det; sb += GW * 64) {
         const int k = sb + tid;
@@ -388,7 +428,7 @@ size_t nms_workspace_bytes(int B, int N, int nc, int multi_label, long* cap_out)
     size_t bytes = 0;
     bytes += ((size_t)B * nblk * sizeof(int) + 255) / 256 * 256;
     bytes += ((size_t)B * sizeof(int) + 255) / 256 * 256;
-    bytes += (size_t)B * cap * sizeof(unsigned long long);
+    bytes += (size_t)2 * B * cap * sizeof(unsigned long long);
     bytes += (size_t)B * cap * 4 * sizeof(float);
     return bytes;
 }
@@ -406,11 +446,11 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
         const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(nms_sort_lds_kernel), CHUNK * 8, a.device, attr);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 1, 0L);
-    for (long k = 2L * CHUNK; k <= a.cap; k <<= 1) {
-        for (long j = k >> 1; j >= CHUNK; j >>= 1)
-            hipLaunchKernelGGL(nms_sort_global_kernel, dim3((unsigned)std::min<long>((a.cap / 2 + 255) / 256, 64), a.B), dim3(256), 0, s, a, k, j);
-        hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a, 0, k);
+    hipLaunchKernelGGL(nms_sort_lds_kernel, dim3(chunks, a.B), dim3(SORT_T), CHUNK * 8, s, a);
+    {
+        int level = 1;
+        for (long R = CHUNK; R < a.cap; R <<= 1, ++level)
+            hipLaunchKernelGGL(nms_merge_kernel, dim3((unsigned)std::min<long>((a.cap + MWG - 1) / MWG, 64), a.B), dim3(256), 0, s, a, R, level);
     }
     const size_t glds = (size_t)a.max_det * 5 * sizeof(float) + 2 * sizeof(int) + 64 * 5 * sizeof(float);
     if (glds > 48 * 1024) {         // max_detections above ~2400: the kept list needs more than the default dynamic LDS limit

@@ -251,6 +251,7 @@ struct NmsArgs {
     int* blk_counts;    // [B, nblk]
     int* totals;        // [B]
     unsigned long long* keys;  // [B, cap]
+    unsigned long long* keys2; // [B, cap]: the other buffer of the merge levels
     float* cand;        // [B, cap, 4]  (score, conf, class, src row as int bits)
     long cap;           // power of two >= N * (multi_label ? nc : 1)
     int device;         // device ordinal of the handle (per-device LDS attribute)
