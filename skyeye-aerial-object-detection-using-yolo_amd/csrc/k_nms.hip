@@ -4,7 +4,7 @@
 // delegates to torchvision.ops.nms (call site metrics.py:442; semantics restated in oracle/sky_oracle_nms.c).
 //
 //   1. count    per 256-row block: how many candidate entries the rows produce   (metrics.py:389,402-422,425-426)
-//   2. scan     exclusive scan of the block counts per image (deterministic, ordered compaction - no atomics)
+//   2. (scan)   every emit block adds up the counts of the blocks before it (deterministic, ordered compaction - no atomics)
 //   3. emit     candidate records in (row, class) order + 64-bit sort keys
 //               key = ~monotone(score) << 32 | candidate index  => ascending key order is "score descending,
 //               lower index first", the tie rule fixed by this build
@@ -109,46 +109,46 @@ __global__ void __launch_bounds__(ROWS) nms_count_kernel(const NmsArgs a, int nb
     }
 }
 
-// in-place exclusive scan of blk_counts[b][0..nblk); totals[b] = sum.  One block of 256 threads per image.
-__global__ void __launch_bounds__(256) nms_scan_kernel(const NmsArgs a, int nblk)
-{
-    const int b = blockIdx.x, t = threadIdx.x;
-    int* c = a.blk_counts + (long)b * nblk;
-    const int per = (nblk + 255) / 256;
-    const int i0 = t * per, i1 = (i0 + per < nblk) ? i0 + per : nblk;
-    int s = 0;
-    for (int i = i0; i < i1; ++i) s += c[i];
-    __shared__ int part[256];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = run; run += v; }
-        a.totals[b] = run;
-    }
-    __syncthreads();
-    int run = part[t];
-    for (int i = i0; i < i1; ++i) { const int v = c[i]; c[i] = run; run += v; }
-}
-
+// Candidate records + sort keys of one 256-row block, in (row, class) order.  The block's first slot = the sum of the counts of the
+// blocks before it (every block adds them up itself: at most a few hundred integers from L2, cheaper than a scan launch); block 0
+// also publishes the image's total.  Inside the block: wave scans by shuffles, wave offsets through LDS.
 __global__ void __launch_bounds__(ROWS) nms_emit_kernel(const NmsArgs a, int nblk)
 {
-    const int b = blockIdx.y, blk = blockIdx.x;
-    const int i = blk * ROWS + threadIdx.x;
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blk * ROWS + tid;
     const float* p = a.det + ((long)b * a.N + i) * (a.nc + 5);
     int cnt = 0;
     if (i < a.N) row_entries(a, p, [&](float, float, float) { ++cnt; });
-    // exclusive scan of cnt over the block (row order)
-    __shared__ int sc[ROWS];
-    sc[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int o = 1; o < ROWS; o <<= 1) {
-        const int v = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
-        __syncthreads();
-        sc[threadIdx.x] += v;
-        __syncthreads();
+    __shared__ int red[3][ROWS / 64];
+    // counts of the blocks before this one (and, in block 0, of all blocks)
+    const int* c = a.blk_counts + (long)b * nblk;
+    int pre = 0, tot = 0;
+    for (int j = tid; j < nblk; j += ROWS) {
+        const int v = c[j];
+        tot += v;
+        pre += j < blk ? v : 0;
     }
-    long k = (long)a.blk_counts[(long)b * nblk + blk] + (sc[threadIdx.x] - cnt);
+    // inclusive scan of cnt over the wave
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); tot += __shfl_xor(tot, o); }
+    if (lane == 63) red[0][wave] = inc;
+    if (lane == 0) { red[1][wave] = pre; red[2][wave] = tot; }
+    __syncthreads();
+    int base = 0, woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < ROWS / 64; ++w) {
+        base += red[1][w];
+        total += red[2][w];
+        woff += w < wave ? red[0][w] : 0;
+    }
+    if (blk == 0 && tid == 0) a.totals[b] = total;
+    long k = (long)base + woff + (inc - cnt);
     if (i < a.N && cnt) {
         row_entries(a, p, [&](float score, float c5, float c6) {
             if (k < a.cap) {
@@ -168,16 +168,6 @@ __device__ __forceinline__ long padded_len(int total)
     return p;
 }
 
-// keys[total .. padded) = ~0 so they sort last
-__global__ void __launch_bounds__(256) nms_pad_kernel(const NmsArgs a)
-{
-    const int b = blockIdx.y;
-    const int total = a.totals[b];
-    const long P = padded_len(total);
-    const long end = P < a.cap ? P : a.cap;
-    for (long k = total + (long)blockIdx.x * 256 + threadIdx.x; k < end; k += (long)gridDim.x * 256) a.keys[(long)b * a.cap + k] = ~0ull;
-}
-
 // Bitonic sort of one chunk of CHUNK keys inside LDS, ascending (the direction of a compare-exchange comes from the element's index
 // INSIDE the chunk, so every chunk ends ascending: the merge levels below want sorted runs, not a bitonic sequence).
 __global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a)
@@ -189,7 +179,8 @@ __global__ void __launch_bounds__(SORT_T) nms_sort_lds_kernel(const NmsArgs a)
     const long len = P < CHUNK ? P : CHUNK;
     extern __shared__ unsigned long long sk[];   // CHUNK keys
     unsigned long long* g = a.keys + (long)b * a.cap + base;
-    for (int i = threadIdx.x; i < len; i += SORT_T) sk[i] = g[i];
+    const long total = a.totals[b];
+    for (int i = threadIdx.x; i < len; i += SORT_T) sk[i] = base + i < total ? g[i] : ~0ull;       // keys [total, P) = ~0: they sort last
     __syncthreads();
     const int half = (int)(len >> 1);
     for (long k = 2; k <= len; k <<= 1) {
@@ -437,9 +428,7 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s)
 {
     const int nblk = (a.N + ROWS - 1) / ROWS;
     hipLaunchKernelGGL(nms_count_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(a.B), dim3(256), 0, s, a, nblk);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(nblk, a.B), dim3(ROWS), 0, s, a, nblk);
-    hipLaunchKernelGGL(nms_pad_kernel, dim3((unsigned)std::min<long>((a.cap + 255) / 256, 16), a.B), dim3(256), 0, s, a);
     const unsigned chunks = (unsigned)((a.cap + CHUNK - 1) / CHUNK);
     static size_t attr[16] = {0};
     {
