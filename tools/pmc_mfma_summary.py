@@ -19,6 +19,8 @@ def family(k):
         return "stem_down"
     if "csp_stage_kernel" in k:
         return "csp_stage"
+    if "head_stream_kernel" in k:
+        return "tile"                # detection levels: same family as the tile kernel's head launches
     if "conv_halo_kernel" in k and (re.search(r"Lb1EEEvNS_8ConvArgsE$", k.split("(")[0]) or re.search(r", true>$", k.split("(")[0])):
         return "halo_cv1"            # last template argument CV1 = true: the fused bottleneck
     if "conv_halo_small" in k:

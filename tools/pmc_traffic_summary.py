@@ -32,6 +32,8 @@ for k, v in agg.items():
         variant = 8064
     elif "csp_stage_kernel" in k:
         variant = 8564
+    elif "head_stream_kernel" in k:
+        variant = 1548
     elif "conv_halo_kernel" in k:
         # <T, NF, SQ, S2, FC, TO, CV1> (mangled or demangled); CV1 = fused bottleneck (7064)
         mh = re.search(r"conv_halo_kernelI(?:DF16b|f|NS_5fp8_tE)Li(\d)ELb(\d)ELb(\d)ELi(\d+)E(?:DF16b|f|NS_5fp8_tE|S1_)Lb(\d)E", k)
