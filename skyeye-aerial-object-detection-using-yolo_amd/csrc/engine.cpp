@@ -2171,7 +2171,9 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
         long cap = 0;
         const size_t need = nms_workspace_bytes(B, N, nc, a.multi_label, &cap);
         if (need > h->e.nms_ws_bytes) {
-            if (h->e.nms_ws) (void)hipFree(h->e.nms_ws);
+            // A smaller workspace is retired, not freed: a captured hipGraph may still replay launches that point into it
+            // (it goes with the handle, like every other device allocation of the plan).
+            if (h->e.nms_ws) h->e.owned.push_back(h->e.nms_ws);
             h->e.nms_ws = nullptr;
             SKY_HIP(hipMalloc(&h->e.nms_ws, need));
             h->e.nms_ws_bytes = need;
