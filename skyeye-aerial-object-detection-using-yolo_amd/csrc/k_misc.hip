@@ -689,37 +689,48 @@ hipError_t launch_sa_stats(int dtype, const void* x, int ld, const float* att, i
 }
 
 // gate[b, y, x] = sigmoid(conv7x7(stats)) with weights w[0][ch][ky][kx], ch 0 = mean, 1 = max (attention.py:79,95-96)
-__global__ void sa_gate_kernel(const float* __restrict__ stats, const float* __restrict__ w, int B, int H, int W,
-                               float* __restrict__ gate)
+// One workgroup per 16 x 16 tile of an image: the 22 x 22 x 2 window of the statistics goes to LDS once (zeros outside the image: a
+// skipped tap and a tap times zero leave the same sum), the 98 taps of a pixel then run from LDS in the order (ch, ky, kx).
+__global__ void __launch_bounds__(256) sa_gate_kernel(const float* __restrict__ stats, const float* __restrict__ w, int B, int H, int W,
+                                                      float* __restrict__ gate)
 {
     __shared__ float ws[98];
+    __shared__ float st[2][22][23];
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, b = t2 / tiles_y;
     if (threadIdx.x < 98) ws[threadIdx.x] = w[threadIdx.x];
-    __syncthreads();
-    const long total = (long)B * H * W;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(p % W);
-        const long t = p / W;
-        const int y = (int)(t % H);
-        const int b = (int)(t / H);
-        float acc = 0.0f;
-        for (int ch = 0; ch < 2; ++ch)
-            for (int ky = 0; ky < 7; ++ky) {
-                const int yy = y + ky - 3;
-                if ((unsigned)yy >= (unsigned)H) continue;
-                for (int kx = 0; kx < 7; ++kx) {
-                    const int xx = x + kx - 3;
-                    if ((unsigned)xx >= (unsigned)W) continue;
-                    acc += ws[(ch * 7 + ky) * 7 + kx] * stats[(((long)b * H + yy) * W + xx) * 2 + ch];
-                }
-            }
-        gate[p] = 1.0f / (1.0f + expf(-acc));
+    for (int i = threadIdx.x; i < 22 * 22; i += 256) {
+        const int ly = i / 22, lx = i - ly * 22;
+        const int yy = ty * 16 + ly - 3, xx = tx * 16 + lx - 3;
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const float* p = stats + (((long)b * H + yy) * W + xx) * 2;
+        st[0][ly][lx] = ok ? p[0] : 0.0f;
+        st[1][ly][lx] = ok ? p[1] : 0.0f;
     }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int y = ty * 16 + ly, x = tx * 16 + lx;
+    if (y >= H || x >= W) return;
+    float acc = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int yy = y + ky - 3, xx = x + kx - 3;
+                // (same sum as skipping the taps outside the image: they add an exact zero)
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) acc += ws[(ch * 7 + ky) * 7 + kx] * st[ch][ly + ky][lx + kx];
+            }
+    gate[((long)b * H + y) * W + x] = 1.0f / (1.0f + expf(-acc));
 }
 
 hipError_t launch_sa_gate(const float* stats, const float* w, int B, int H, int W, float* gate, hipStream_t s)
 {
-    const long total = (long)B * H * W;
-    hipLaunchKernelGGL(sa_gate_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, s, stats, w, B, H, W, gate);
+    const long tiles = (long)B * ((H + 15) / 16) * ((W + 15) / 16);
+    if (tiles > 2147483647L) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sa_gate_kernel, dim3((unsigned)tiles), dim3(256), 0, s, stats, w, B, H, W, gate);
     return hipGetLastError();
 }
 
