@@ -503,6 +503,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
         dbg_stamp(a, stamps, nth, 0);
         if ((SKY_DBG(a) & 256) && nth == 1 && threadIdx.x == 0) stamps[60] = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference clock
         if ((SKY_DBG(a) & 256) && nth == 0 && threadIdx.x == 0) { stamps[56] = __builtin_amdgcn_s_memtime(); stamps[57] = __builtin_amdgcn_s_memrealtime(); }
+        __builtin_amdgcn_s_setprio(1);                 // tap phase: this wave's MFMAs ahead of the other workgroup's epilogue arithmetic
         for (int g = 0; g < G; ++g) {
             const TapStep st = tap_step<S2>(q);
             if (st.newhalo && g > 0) {
@@ -535,6 +536,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             if (!(SKY_DBG(a) & 4)) { issue_w(first.tap, 0, 0); issue_w(second.tap, 0, 1); }
         }
         dbg_stamp(a, stamps, nth, 41);
+        __builtin_amdgcn_s_setprio(0);
         if (!(SKY_DBG(a) & 8)) epilogue_act(bimg, y0, x0);
         dbg_stamp(a, stamps, nth, 42);
         if ((SKY_DBG(a) & 256) && nth == 1 && threadIdx.x == 0) stamps[61] = __builtin_amdgcn_s_memrealtime();
