@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
     float* const bb2 = bb1 + HD;
     float* const b3 = bb2 + HD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: LDS-DMA targets, branches)
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_x = (a.W + TS - 1) / TS, tiles_y = (a.H + TS - 1) / TS;
     const int ntile = a.B * tiles_y * tiles_x;
