@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(b2lds + (FC ? FC : 0));   // 64 x 8 B, experiments only
     float* const b1lds = reinterpret_cast<float*>(stamps + 64);                   // CV1: b1 [NB] (behind the 512 bytes of experiment stamps)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: no waterfall around the LDS-DMA)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: scalar LDS-DMA targets, no v_readfirstlane -> m0 chain per piece)
     const int fr = lane & 15, fq = lane >> 4;
     const int Cb = a.Cin * (int)sizeof(T);
     const int nchunk = Cb >> 7;
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     unsigned char* const rawl = reinterpret_cast<unsigned char*>(lbias + NBS);
     T* const lut = reinterpret_cast<T*>(rawl + RAW_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: no waterfall around the LDS-DMA)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: scalar LDS-DMA targets, no v_readfirstlane -> m0 chain per piece)
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.y * NB;
     const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
     char* const wlds = smem;
     char* const hlds = smem + NSLAB * WBUF;
     float* const lbias = reinterpret_cast<float*>(smem + NSLAB * WBUF + 2 * HB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: no waterfall around the LDS-DMA)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: scalar LDS-DMA targets, no v_readfirstlane -> m0 chain per piece)
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.y * NB;
     const int tile_w = SQ ? 16 : a.tile_w, tile_h = SQ ? 16 : a.tile_h;
