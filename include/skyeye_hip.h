@@ -158,6 +158,9 @@ typedef struct sky_handle sky_handle;
 
 /* Library / device probes (no compute). */
 int sky_abi_version(void);
+/* "<16 hex digits>": sha-256 prefix of the sources (csrc/ *.hip, *.h, engine.cpp, Makefile, this header) the loaded library was built
+ * from; bench.py / smoke() print it and __graft_entry__.build() compares it with the working tree (round 2 measured a stale object). */
+const char* sky_build_info(void);
 int sky_device_count(void);
 const char* sky_last_error(const sky_handle* h);
 

@@ -14,6 +14,7 @@
 // 256 MiB Infinity Cache to serve producer->consumer traffic at small batch.
 #include "../../include/skyeye_hip.h"
 #include "sky_kernels.h"
+#include "build_hash.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1831,6 +1832,8 @@ static int guarded(sky_handle* h, F&& f)
 extern "C" {
 
 int sky_abi_version(void) { return SKY_ABI_VERSION; }
+
+const char* sky_build_info(void) { return SKY_SOURCE_HASH; }
 
 int sky_device_count(void)
 {

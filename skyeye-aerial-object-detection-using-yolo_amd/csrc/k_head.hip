@@ -93,7 +93,8 @@ __global__ void __launch_bounds__(hd::NT) head_stream_kernel(const ConvArgs a)
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int i = 0; i < MF; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+        // (runtime trip count and a convergent body: hipcc does not partially unroll this loop; the MF loads of a step are in flight together)
+#pragma unroll 1
         for (int ks = 0; ks < KS; ++ks) {
             u32x4_t pf[MF];
 #pragma unroll

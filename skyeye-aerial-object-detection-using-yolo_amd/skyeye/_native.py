@@ -55,7 +55,7 @@ class SkyNmsParams(ctypes.Structure):
 
 
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
-SYMBOLS = ["sky_abi_version", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
+SYMBOLS = ["sky_abi_version", "sky_build_info", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
            "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_offset_boxes", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_packed_scales", "sky_calibrate", "sky_num_scales", "sky_scales_read", "sky_scales_write", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
 
@@ -83,6 +83,7 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     vp, ip = ctypes.c_void_p, ctypes.c_int
     L.sky_abi_version.restype = ip
+    L.sky_build_info.restype = ctypes.c_char_p
     L.sky_device_count.restype = ip
     L.sky_last_error.restype = ctypes.c_char_p
     L.sky_last_error.argtypes = [vp]
@@ -123,6 +124,27 @@ def lib():
     L.sky_tile_gather.argtypes = [vp, vp, ip, ip, ip, vp, ip, vp, ip, ip, ip, ip, vp]
     _lib = L
     return L
+
+
+def build_info():
+    """Hash of the sources the LOADED library was built from (sky_build_info)."""
+    return lib().sky_build_info().decode()
+
+
+def source_hash():
+    """The same hash computed from the working tree (csrc/Makefile: build_hash.h), or None where csrc/ did not travel."""
+    import glob
+    import hashlib
+    csrc = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+    if not os.path.exists(os.path.join(csrc, "engine.cpp")):
+        return None
+    names = [os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))]
+    names = sorted(set(n for n in names if n != "build_hash.h") | {"engine.cpp", "Makefile", "../../include/skyeye_hip.h"})
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(csrc, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc, handle=None):
