@@ -167,6 +167,7 @@ struct Engine {
     int n_cu = 256;         // compute units of cfg.device
 
     bool calibrated = false;    // fp8: activation scales are set
+    unsigned mask_opts = 0;     // PlanOpt bits this plan must not take from the environment (the calibration twin of an fp8 plan)
     int esize() const { return dtype_size(dtype); }
     int epc() const { return 16 / dtype_size(dtype); }
     void free_plan()
@@ -1697,7 +1698,7 @@ static void plan_section(Engine& e)
 static void plan(Engine& e, const Geometry& g)
 {
     e.free_plan();
-    e.opts = read_plan_opts() | e.extra_opts;
+    e.opts = (read_plan_opts() | e.extra_opts) & ~e.mask_opts;
     if (e.dtype == SKY_FP8) e.opts &= ~(unsigned)OPT_FUSE;
     {
         hipDeviceProp_t prop;
@@ -1761,6 +1762,7 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
     tw.dtype = SKY_BF16;
     tw.weights = e.weights;
     tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN | OPT_NO_CSP_STAGE;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
+    tw.mask_opts = OPT_FUSE;            // like the fp8 plan itself: an op computed in its producer's epilogue would never reach its amax reduction
     plan(tw, geometry_of(n_inputs, inputs));
     if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");
     std::vector<sky_buffer> outs(tw.out_info.size());
@@ -1790,6 +1792,17 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
         std::vector<float> host(tw.bufs.size());
         SKY_HIP(hipMemcpyAsync(host.data(), amax, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
         SKY_HIP(hipStreamSynchronize(s));
+        {   // an fp8 tensor some launch writes and whose range was never seen would silently get scale 1 (saturation at 448 or lost range)
+            std::vector<char> written(tw.bufs.size(), 0);
+            for (const Op& op : tw.ops)
+                if (op.out.buf >= 0 && op.out.B > 0) written[op.out.buf] = 1;
+            bool all_zero = true;
+            for (size_t i = 0; i < host.size(); ++i) all_zero = all_zero && !(host[i] > 0.0f);
+            for (size_t i = 0; i < e.bufs.size() && !all_zero; ++i)
+                if (e.bufs[i].dt == SKY_FP8 && written[i] && !(host[i] > 0.0f))
+                    throw Error(SKY_ERR_STATE, "sky_calibrate: workspace tensor " + std::to_string(i) + " is written by the graph but its range was not measured "
+                                               "(all zeros on the calibration input, or a launch that skipped its amax reduction)");
+        }
         for (size_t i = 0; i < e.bufs.size(); ++i) e.bufs[i].scale = (e.bufs[i].dt == SKY_FP8 && host[i] > 0.0f) ? host[i] / 448.0f : 1.0f;
         for (size_t i = 0; i < e.bufs.size(); ++i) {        // tied buffers: the root carries the larger range
             int r = (int)i;
@@ -1944,8 +1957,15 @@ static void check_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs,
     std::vector<char> optional(n_outputs, 0);
     for (const Op& op : h->e.ops)
         if (op.kind == OP_CONV && op.head && op.raw_ext >= 16 && op.raw_ext - 16 < n_outputs) optional[op.raw_ext - 16] = 1;
-    for (int i = 0; i < n_outputs; ++i)
+    for (int i = 0; i < n_outputs; ++i) {
         if (!outputs[i].data && !optional[i]) throw Error(SKY_ERR_INVALID, "sky_forward: null output");
+        if (!outputs[i].data) continue;
+        // a caller-side cache that hands over the buffers of another geometry must fail here, not write past their end
+        const IoInfo& oi = h->e.out_info[i];
+        bool same = outputs[i].ndim == oi.ndim;
+        for (int k = 0; same && k < oi.ndim; ++k) same = outputs[i].shape[k] == oi.shape[k];
+        if (!same) throw Error(SKY_ERR_SHAPE, "sky_forward: output " + std::to_string(i) + " has another shape than the plan's (sky_output_info)");
+    }
 }
 
 int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_outputs, const sky_buffer* outputs, void* stream)

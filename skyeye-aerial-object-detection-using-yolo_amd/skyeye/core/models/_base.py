@@ -124,7 +124,7 @@ class NativeModule(nn.Module):
         self.__dict__["_engines"] = {}      # (precision, device, shapes, switches) -> (Handle, weights fingerprint)
         self.__dict__["_weights_version"] = 0
         self.__dict__["_precision"] = None   # None: follow parameter dtype (fp32 -> exact, half/bf16 -> bf16)
-        self.__dict__["_out_cache"] = None   # reuse_output_buffers(True): {engine key: output tensors}
+        self.__dict__["_out_cache"] = None   # reuse_output_buffers(True): {engine key (NOT id(handle): ids are recycled): output tensors}
 
     def __setattr__(self, name, value):
         if isinstance(value, torch.Tensor):
@@ -198,9 +198,16 @@ class NativeModule(nn.Module):
         self.__dict__["_calib_inputs"] = frames
         for key, (h, fp) in list(self._engines.items()):
             if key[0] == "fp8":
-                h.close()
-                del self._engines[key]
+                self._drop_engine(key)
         return self
+
+    def _drop_engine(self, key):
+        """Close a plan and forget everything that was cached for it (its reusable output tensors)."""
+        ent = self._engines.pop(key, None)
+        if ent is not None:
+            ent[0].close()
+        if self._out_cache is not None:
+            self._out_cache.pop(key, None)
 
     def half(self):
         """Reference callers use model.half() for the reduced-precision path (validate.py:195-197, detect.py:107-108).
@@ -238,6 +245,10 @@ class NativeModule(nn.Module):
             h.close()
 
     def _engine(self, inputs, extra_cfg=None):
+        return self._engine_entry(inputs, extra_cfg)[1]
+
+    def _engine_entry(self, inputs, extra_cfg=None):
+        """(cache key, Handle) of the plan for these inputs."""
         prec = self._resolved_precision()
         dev = inputs[0].device
         key = (prec, dev.index or 0, tuple(tuple(t.shape) for t in inputs), tuple(sorted((extra_cfg or {}).items())),
@@ -245,14 +256,11 @@ class NativeModule(nn.Module):
         fp = self._weights_fingerprint()
         ent = self._engines.get(key)
         if ent is not None and ent[1] == fp:
-            return ent[0]
+            return key, ent[0]
         if ent is not None:
-            ent[0].close()
-            if self._out_cache is not None:
-                self._out_cache.pop(id(ent[0]), None)
+            self._drop_engine(key)
         if len(self._engines) >= 6:                       # keep a few geometries resident (test-time augmentation plans three)
-            old, _ = self._engines.pop(next(iter(self._engines)))     # the oldest plan goes first
-            old.close()
+            self._drop_engine(next(iter(self._engines)))  # the oldest plan goes first
         cfg = dict(self._sky_config())
         cfg.update(extra_cfg or {})
         h = N.Handle(N.make_config(self._sky_module, dtype=N.DTYPES[prec], device=dev.index or 0, **cfg))
@@ -266,7 +274,7 @@ class NativeModule(nn.Module):
                 cal = inputs                       # self-calibration on the first batch of this geometry
             h.calibrate([N.buffer_from_tensor(t) for t in cal], torch.cuda.current_stream(dev).cuda_stream)
         self._engines[key] = (h, fp)
-        return h
+        return key, h
 
     def export_engine(self, path, *example_inputs):
         """Write the engine's own weight file for the geometry of ``example_inputs`` (export.py counterpart):
@@ -300,14 +308,14 @@ class NativeModule(nn.Module):
         """``skip``: indices of optional outputs the caller does not want (the raw detection levels): the engine gets a NULL
         buffer for them and does not write them; the returned list holds None there."""
         inputs = [self._prepare_input(t) for t in inputs]
-        h = self._engine(inputs, extra_cfg)
+        key, h = self._engine_entry(inputs, extra_cfg)
         cache = self._out_cache
-        outs = cache.get(id(h)) if cache is not None else None
+        outs = cache.get(key) if cache is not None else None
         if outs is None or any((o is None) != (i in skip) for i, o in enumerate(outs)):
             outs = [None if i in skip else torch.empty(s, dtype=torch.float32, device=inputs[0].device)
                     for i, s in enumerate(h.output_shapes())]
             if cache is not None:
-                cache[id(h)] = outs
+                cache[key] = outs
         stream = torch.cuda.current_stream(inputs[0].device).cuda_stream
         h.forward([N.buffer_from_tensor(t) for t in inputs],
                   [N.null_buffer() if t is None else N.buffer_from_tensor(t) for t in outs], stream)

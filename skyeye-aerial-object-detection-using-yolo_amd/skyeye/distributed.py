@@ -45,12 +45,14 @@ def all_gather_detections(rows, counts, group=None):
         return rows, counts
     packed = pack_detections(rows, counts)
     out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    try:
-        dist.all_gather_into_tensor(out, packed, group=group)
-    except (RuntimeError, NotImplementedError):          # backends without the fused form
+    if dist.get_backend(group) == "gloo" and not packed.is_cuda:
+        # the CPU test backend: list form (gloo has no all_gather_into_tensor for CPU tensors on every build)
         parts = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(parts, packed, group=group)
         out = torch.stack(parts, 0)
+    else:
+        # RCCL: ONE fused collective; an error here is an RCCL / xGMI failure and must surface, not be retried on another path
+        dist.all_gather_into_tensor(out, packed, group=group)
     return unpack_detections(out.reshape(world * packed.shape[0], -1), rows.shape[1], rows.shape[2])
 
 

@@ -11,16 +11,37 @@ import torch
 
 from .. import _native as N
 
-_UTIL = {}
+import collections
+
+_UTIL = collections.OrderedDict()       # (device, stream pointer) -> utility Handle, least recently used first
+_UTIL_MAX = 8
+_KEEP = []                              # stack of lists: capture_graph collects the handles a captured region used
 
 
 def _handle(device_index, stream=0):
-    """One utility handle (it owns the NMS workspace) per (device, stream): two streams never share a workspace."""
-    h = _UTIL.get((device_index, stream))
+    """One utility handle (it owns the NMS workspace, tens of MB) per (device, stream): two streams never share a workspace.
+
+    The table is a small LRU: a stream pointer can be recycled by a NEW stream after the old one is destroyed, and every
+    ``capture_graph`` call makes a fresh stream, so entries must not pile up.  An evicted handle is only dropped here; it is
+    closed when its last owner lets go of it.  A captured hipGraph replays into the workspace of the handle it was captured
+    with: ``capture_graph`` therefore keeps that handle alive with the graph (``graph._sky_keep``), whatever this table does."""
+    key = (device_index, stream)
+    h = _UTIL.get(key)
     if h is None:
         h = N.Handle(N.make_config("UTILITY", device=device_index))
-        _UTIL[(device_index, stream)] = h
+        _UTIL[key] = h
+        while len(_UTIL) > _UTIL_MAX:
+            _UTIL.popitem(last=False)
+    else:
+        _UTIL.move_to_end(key)
+    if _KEEP:
+        _KEEP[-1].append(h)
     return h
+
+
+def forget_stream(device_index, stream):
+    """Drop the utility handle of a stream that is going away (its pointer may be handed to a new stream)."""
+    _UTIL.pop((device_index, stream), None)
 
 
 def nms_raw(prediction, conf_threshold=0.25, iou_threshold=0.45, classes=None, agnostic=False, multi_label=False,

@@ -62,14 +62,24 @@ def capture_graph(fn, warmup=2):
     must keep their storage; to feed new frames copy them into the captured input tensor."""
     if not torch.cuda.is_available():
         raise N.SkyEyeNativeError("capture_graph needs the HIP device (no CPU path)")
+    from . import metrics as _metrics
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(1, warmup)):
-            fn()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
-        outputs = fn()
+    keep = []
+    _metrics._KEEP.append(keep)
+    try:
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            outputs = fn()
+    finally:
+        _metrics._KEEP.pop()
+    # the graph replays into the NMS workspace of the utility handle(s) it was captured with: they live as long as the graph; the
+    # capture stream dies with this call, so its table entry goes (a new stream may get the same pointer)
+    graph._sky_keep = keep
+    _metrics.forget_stream(torch.cuda.current_device(), side.cuda_stream)
     return graph, outputs
