@@ -1158,6 +1158,7 @@ static bool cv1_shape_ok(int dtype, ConvArgs& a)
 {
     if (dtype != 1 || (a.out_dt >= 0 && a.out_dt != 1)) return false;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2 || a.src_mode || a.f2_w) return false;
+    if (a.Cin == 128 && a.Cout == 128) return bneck128_shape_ok(a);          // the 128-channel bottleneck kernel (k_bneck.hip)
     if (a.Cin != 64 || a.Cout != 64 || a.c1_Kpad < 64) return false;
     if (a.in_bytes == 0 || a.out_bytes == 0) return false;
     if ((long)a.Kpad * 2 < 9L * 128 || (a.opts & (OPT_HALO_OFF | OPT_NO_FUSE_CV1))) return false;
@@ -1177,6 +1178,11 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     ConvArgs a = a0;
     if (a.c1_w) {       // planned as a fused bottleneck: there is no other kernel for this op
         if (!cv1_shape_ok(dtype, a)) return hipErrorInvalidValue;
+        if (a.Cin == 128) {
+            const hipError_t e0 = launch_bneck128(a, s);
+            if (e0 == hipSuccess && variant) *variant = 7128;
+            return e0;
+        }
         const int n_cu1 = a.n_cu > 0 ? a.n_cu : 256;
         const bool sq1 = a.tile_w == 16 && a.tile_h == 16;
         const hipError_t e1 = sq1 ? halo_launch<__bf16, 4, true, false, 0, __bf16, true>(a, s, n_cu1) : halo_launch<__bf16, 4, false, false, 0, __bf16, true>(a, s, n_cu1);

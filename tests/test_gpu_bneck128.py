@@ -1,0 +1,62 @@
+"""BottleneckBlock(128, 128) as ONE kernel (k_bneck.hip: cv1 on the halo tile, u kept in LDS, weights through a four-stage ring with
+counted waits): bit-identical to the two-launch form (SKY_NO_BNECK128=1: 1x1 on the streaming kernel + 3x3 with residual on the
+halo-tile kernel) -- same MFMA instructions in the same K order, same bf16 roundings -- on CSP blocks with 2, 3 and 4 bottlenecks,
+ragged maps (image borders inside tiles), the 80 x 80 size of the detector at B = 32 (several tiles per workgroup, the ring running
+across tile boundaries) and the single-tile / last-tile cases; deterministic; close to the fp32 engine."""
+import os
+
+import pytest
+import torch
+
+import skyeye.core.models as M
+from helpers import load_seeded
+from seeded import seeded_input
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(3, 2, 48, 48), (2, 1, 16, 16), (2, 2, 40, 56), (4, 1, 33, 47), (3, 32, 80, 80), (3, 2, 24, 100), (2, 3, 160, 160)]
+
+
+def _run(n, x, fused, shortcut=True):
+    m = load_seeded(M.CSPBlock(256, 256, num_blocks=n, shortcut=shortcut), 23).set_precision("bf16")
+    if not fused:
+        os.environ["SKY_NO_BNECK128"] = "1"
+    os.environ["SKY_CONV_HALO"] = "force"         # ragged maps: both forms take the halo-tile kernels whatever the tile fill
+    try:
+        y = m(x)
+        h = m._engine([x])
+        info = [h.op_info(i) for i in range(h.stats()["launches"])]
+    finally:
+        os.environ.pop("SKY_NO_BNECK128", None)
+        os.environ.pop("SKY_CONV_HALO", None)
+    return y, info
+
+
+@pytest.mark.parametrize("case", CASES, ids=["n%d_b%d_%dx%d" % c for c in CASES])
+def test_bneck128_equals_two_launch_form(case):
+    n, B, H, W = case
+    x = torch.from_numpy(seeded_input("bk128.x.%d.%d" % (H, W), (B, 256, H, W), 3, -2.0, 2.0)).cuda()
+    yf, info_f = _run(n, x, True)
+    yu, info_u = _run(n, x, False)
+    assert sum("bneck128" in t for t in info_f) == n, info_f              # the fused kernel really ran, once per bottleneck
+    assert not any("bneck128" in t for t in info_u) and len(info_u) == len(info_f) + n, info_u
+    assert bool(torch.isfinite(yf).all())
+    assert torch.equal(yf, yu), f"{int((yf != yu).sum())} of {yf.numel()} values differ, max {float((yf - yu).abs().max())}"
+    yf2, _ = _run(n, x, True)
+    assert torch.equal(yf, yf2)
+
+
+def test_bneck128_without_shortcut():
+    x = torch.from_numpy(seeded_input("bk128.ns", (2, 256, 40, 40), 7, -2.0, 2.0)).cuda()
+    yf, info_f = _run(2, x, True, shortcut=False)
+    yu, _ = _run(2, x, False, shortcut=False)
+    assert sum("bneck128" in t for t in info_f) == 2
+    assert torch.equal(yf, yu)
+
+
+def test_bneck128_against_fp32_engine():
+    x = torch.from_numpy(seeded_input("bk128.ref", (2, 256, 64, 64), 5, -2.0, 2.0)).cuda()
+    yf, _ = _run(3, x, True)
+    ref = load_seeded(M.CSPBlock(256, 256, num_blocks=3), 23).set_precision("fp32")(x)
+    err = float((yf - ref).abs().max() / ref.abs().max())
+    assert err < 0.03, err
