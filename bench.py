@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--with-raw", action="store_true", help="also write the three raw detection levels (the reference's second return value)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 (shard), 5 (shard) behind the headline measurement")
     return ap.parse_args()
 
 
@@ -133,6 +134,17 @@ def family_of(tag):
     return "conv_other"
 
 
+def _native_build():
+    """Hash of the sources libskyeye_hip.so was built from (sky_build_info) and whether it equals the working tree's."""
+    from skyeye import _native
+    src = _native.source_hash()
+    return {"library_sources": _native.build_info(), "matches_tree": None if src is None else src == _native.build_info()}
+
+
+OTHER_CONFIGS = [   # BASELINE.json configs[2], [3] (one GPU's shard), [4] (one GPU's shard): short legs behind the headline measurement
+    ("skyeye_s_ha", "bf16", 1280), ("skyeye_l", "bf16", 1280), ("skyeye_l", "fp8", 1536)]
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -162,50 +174,58 @@ def main():
     from skyeye.utils.torch_utils import capture_graph
     from skyeye.distributed import all_gather_detections
 
-    model, P = build_model(a.model, a.precision, dev)
-    B, S = a.batch, a.size
-    frames_np = np.random.default_rng(rank).integers(0, 256, size=(B, 3, S, S), dtype=np.uint8)
-    x = torch.from_numpy(frames_np).to(dev)
-    if a.precision == "fp8":
-        model.calibrate(x[:2])                               # per-tensor activation scales from two frames of the workload
-    shift = calibrate_objectness(model, x, 0.01, a.conf)
-    model.reuse_output_buffers(True)
+    def timed_leg(model_name, precision, size, steps, warmup):
+        """Build + calibrate a detector, capture forward + NMS (+ the RCCL all-gather when world > 1) and time `steps` steps between
+        barriers; returns everything the report needs."""
+        model, P = build_model(model_name, precision, dev)
+        B, S = a.batch, size
+        frames_np = np.random.default_rng(rank).integers(0, 256, size=(B, 3, S, S), dtype=np.uint8)   # BASELINE.md section 4
+        x = torch.from_numpy(frames_np).to(dev)
+        if precision == "fp8":
+            model.calibrate(x[:min(B, 16)])                      # per-tensor activation scales from frames of the workload
+        calibrate_objectness(model, x, 0.01, a.conf)
+        model.reuse_output_buffers(True)
 
-    def local_step():
-        det, _raw = model(x, return_raw=a.with_raw)                             # detector.py:300-324
-        return nms_raw(det, a.conf, a.iou, max_detections=300)                  # metrics.py:361-457, no host sync
+        def local_step():
+            det, _raw = model(x, return_raw=a.with_raw)                             # detector.py:300-324
+            return nms_raw(det, a.conf, a.iou, max_detections=300)                  # metrics.py:361-457, no host sync
 
-    graph = None
-    if not a.no_graph:
-        graph, held = capture_graph(local_step, warmup=2)                       # static shapes: one hipGraph replay per step
+        graph = None
+        if not a.no_graph:
+            graph, held = capture_graph(local_step, warmup=2)                       # static shapes: one hipGraph replay per step
 
-    def step():
-        if graph is not None:
-            graph.replay()
-            rows, counts = held
-        else:
-            rows, counts = local_step()
+        def step():
+            if graph is not None:
+                graph.replay()
+                rows, counts = held
+            else:
+                rows, counts = local_step()
+            if world > 1:
+                rows, counts = all_gather_detections(rows, counts)                  # RCCL over xGMI
+            return rows, counts
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rows, counts = step()
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            rows, counts = all_gather_detections(rows, counts)                  # RCCL over xGMI
-        return rows, counts
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dict(model=model, P=P, x=x, frames_np=frames_np, step=step, graph=graph, dt=dt, counts=counts)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rows, counts = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    leg = timed_leg(a.model, a.precision, a.size, a.steps, a.warmup)
+    model, P, x, frames_np, step, graph, dt, counts = (leg[k] for k in ("model", "P", "x", "frames_np", "step", "graph", "dt", "counts"))
+    B, S = a.batch, a.size
     kept_mean = float(counts.float().mean().item())
 
     # per-batch latency distribution (p50), each step individually synchronised
@@ -246,7 +266,7 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "p50_latency_ms": round(lat[len(lat) // 2], 3), "p99_latency_ms": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 3),
-        "rccl_ranks_seen": ranks_seen,
+        "rccl_ranks_seen": ranks_seen, "build": _native_build(),
         "buckets_ms_per_image": {"pre_process": 0.0, "inference": round(inf_ms / B, 4), "nms": round(nms_ms / B, 4),
                                  "note": "validate.py:323-326 buckets; pre-process (uint8 -> float, /255) is fused into the stem's loader"},
         "nms_worst_case": {"conf": 0.001, "ms_per_batch": round(worst_ms, 3), "ms_per_image": round(worst_ms / B, 4),
@@ -343,6 +363,31 @@ def main():
                                          "CPUs visible; the reference's own PyTorch-CPU path measured ~1.09 frames/s on 8 cores at "
                                          "survey time (BASELINE.md section 2) -- a reported baseline, not the target"}
 
+    # ---- the other configurations of BASELINE.json, 5-step legs (never part of `value`) ----
+    default_headline = a.model == "skyeye_s" and a.precision == "bf16" and S == 1280
+    if default_headline and not a.no_other_configs:
+        del leg, model, step, graph
+        torch.cuda.empty_cache()
+        legs = OTHER_CONFIGS if world == 1 else [("skyeye_l", "bf16", 1280)]      # N > 1: the model the metric names at 8 GPUs
+        others = []
+        for name, prec, size in legs:
+            try:
+                lg = timed_leg(name, prec, size, 5, 2)
+                f = world * B * 5 / lg["dt"]
+                base = name[:-3] if name.endswith("_ha") else name
+                gf = GFLOP_PER_FRAME.get((base, size))
+                others.append({"workload": f"{name} {prec} batch={B}/GPU @{size}x{size}, forward + NMS" + (" + RCCL all-gather" if world > 1 else ""),
+                               "dtype": prec, "frames_per_s": round(f, 1), "ms_per_step": round(lg["dt"] / 5 * 1e3, 3), "steps": 5,
+                               "roofline_frac": round(f / world * gf * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4) if gf else None,
+                               "roofline_note": None if gf else "graph GFLOP per frame not in BASELINE.md for this variant"})
+                del lg
+                torch.cuda.empty_cache()
+            except Exception as ex:  # noqa: BLE001 -- a failing side leg must not lose the headline line
+                others.append({"workload": f"{name} {prec} @{size}", "error": str(ex)[:300]})
+        out["other_configs"] = others
+    if world > 1:
+        out["config"]["scaling_curve_model"] = (f"the N = 1 .. 8 values of this line are {a.model} (BASELINE.json configs[1] replicated per GPU, weak scaling); "
+                                                "the skyeye_l leg the metric names at 8 GPUs is other_configs[0]")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -76,7 +76,12 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
     float* const bb2 = bb1 + HD;
     float* const b3 = bb2 + HD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: LDS-DMA targets, branches)
+    // (wave-uniform: LDS-DMA targets, branches.  SKY_AB_WAVE_VECTOR / SKY_AB_SETPRIO: one-off A/B builds of experiments/README.md)
+#ifdef SKY_AB_WAVE_VECTOR
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#else
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_x = (a.W + TS - 1) / TS, tiles_y = (a.H + TS - 1) / TS;
     const int ntile = a.B * tiles_y * tiles_x;
@@ -134,6 +139,9 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
     int bimg, y0, x0;
     decode_tile(tile, bimg, y0, x0);
     __syncthreads();                                              // weights and biases staged
+#ifdef SKY_AB_SETPRIO
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half
+#endif
     issue_x(bimg, y0, x0);
     for (;;) {
         cs_wait_vmcnt0();

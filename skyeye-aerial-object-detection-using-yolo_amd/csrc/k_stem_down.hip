@@ -142,6 +142,9 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
 
     load_raw(tile);
     __syncthreads();                                              // weights, biases, table staged
+#ifdef SKY_AB_SETPRIO
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);      // one-off A/B build (experiments/README.md)
+#endif
     for (;;) {
         int bimg, y0, x0;
         decode_tile(tile, bimg, y0, x0);

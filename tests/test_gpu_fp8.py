@@ -199,14 +199,26 @@ def test_fp8_detector_agreement_with_fp32_engine(variant, hw, batch):
                          nms_matched_iou50=match50, nms_matched_iou90=match90, nms_mean_iou=miou)
         out[prec] = dict(cls=cls_agree, dobj=obj_mean, row_iou=float(ri.mean()), row90=float((ri > 0.9).mean()), row50=float((ri > 0.5).mean()), nms50=match50, n=n_ref)
     assert out["fp8"]["n"] > 10
-    # Floors = about 0.8 x the lowest value measured over the six cases (r02_b, printed above per case).  These networks have
-    # RANDOM weights: nothing in them damps noise, so the per-layer rounding error (bf16 2^-9, e4m3 2^-4 relative) adds up over
-    # the 75-107 layers -- the bf16 engine's boxes overlap the fp32 engine's by 0.85-0.95 on the same rows, the fp8 engine's by
-    # 0.32-0.61 (16x the per-element error).  What the numbers pin is that the engine computes the fp8 arithmetic it states
-    # (test_fp8_conv_kernels_match_emulation: 99.95 % of outputs bit-equal to the emulation) and does not degrade further.
+    # Floors = 0.9 x the value measured for THIS case in round 3 (printed above per case; profiles/r03_parity_margins.json).  These
+    # networks have RANDOM weights: nothing in them damps noise, so the per-layer rounding error (bf16 2^-9, e4m3 2^-4 relative) adds
+    # up over the 75-107 layers.  tests/test_fp8_sensitivity.py (CPU emulation of the same arithmetic, layer by layer) shows what a
+    # per-layer precision choice could buy: row IoU 0.44 (all fp8) -> 0.75 needs 24 of the 75 layers in bf16, class agreement 0.9
+    # needs 48 -- the early, large layers first.  What the numbers here pin is that the engine computes the fp8 arithmetic it states
+    # (test_fp8_conv_kernels_match_emulation: 99.95 % of outputs bit-equal to the emulation) and does not degrade.
     f, b = out["fp8"], out["bf16"]
-    assert f["cls"] > 0.55 and f["row_iou"] > 0.25 and f["dobj"] < 0.02 and f["row50"] > 0.15, out
+    lo = FP8_ENGINE_FLOORS[(variant, hw)]
+    assert f["cls"] >= lo[0] and f["row_iou"] >= lo[1] and f["row50"] >= lo[2] and f["dobj"] <= lo[3], (out, lo)
     assert b["cls"] > 0.85 and b["row_iou"] > 0.8 and b["row50"] > 0.95 and b["nms50"] > 0.78 and b["dobj"] < 0.002, out
+
+
+FP8_ENGINE_FLOORS = {   # (class agreement, row IoU mean, rows with IoU > 0.5) x 0.9, mean |d obj| x 1.1
+    ("skyeye_s", (256, 256)): (0.773, 0.420, 0.458, 0.0063),
+    ("skyeye_l", (128, 128)): (0.630, 0.547, 0.585, 0.0119),
+    ("skyeye_l", (96, 160)): (0.794, 0.446, 0.423, 0.0124),
+    ("skyeye_l", (640, 640)): (0.626, 0.287, 0.186, 0.0127),
+    ("skyeye_s", (640, 640)): (0.738, 0.482, 0.529, 0.0076),
+    ("skyeye_s", (1280, 1280)): (0.807, 0.511, 0.562, 0.0074),
+}
 
 
 def test_fp8_map_against_fp32_engine():
@@ -229,7 +241,72 @@ def test_fp8_map_against_fp32_engine():
     r8 = SM.mean_average_precision(outs["fp8"], labels)
     r16 = SM.mean_average_precision(outs["bf16"], labels)
     record_agreement("skyeye_s 320 mAP vs fp32 engine", fp8_map50=r8["map50"], fp8_map=r8["map"], bf16_map50=r16["map50"], bf16_map=r16["map"])
-    assert r8["map50"] > 0.08 and r16["map50"] > 0.9 and r16["map"] > 0.75, (r8["map50"], r16["map50"], r16["map"])
+    # floors: 0.9 x measured (round 3: fp8 mAP@.5 0.178, bf16 0.971 / 0.873)
+    assert r8["map50"] > 0.16 and r16["map50"] > 0.87 and r16["map"] > 0.78, (r8["map50"], r16["map50"], r16["map"])
+
+
+@pytest.mark.parametrize("name", ["s_1280", "l_640", "l_1280"])
+def test_fp8_against_sampled_reference_fixture(name):
+    """The fp8 engine against the REFERENCE's own rows at the full sizes (tests/golden/detectors_sampled.npz: outputs of the reference
+    classes, 4 096 sampled rows per case): class argmax and IoU of the decoded boxes on rows where the reference is confident,
+    objectness error, calibrated on the case's own frames (16 where the batch has them).  Rates are printed next to the bf16 engine's
+    (test_gpu_detector.py); the floors are 0.9 x the values measured in round 3 (profiles/r03_*_parity_margins.json)."""
+    from cases import DETECTOR_CASES, variant_of
+    G = os.path.join(ROOT, "tests", "golden")
+    S = np.load(os.path.join(G, "detectors_sampled.npz"))
+    case = [c for c in DETECTOR_CASES if c["name"] == name][0]
+    h, w = case["hw"]
+    frames = seeded_scene(case["batch"], h, w, case["seed"])
+    x = torch.from_numpy(frames).cuda()
+    out = {}
+    for prec in ("bf16", "fp8"):
+        m = _detector(variant_of(case), prec)
+        if prec == "fp8":
+            m.calibrate(x[:16])
+        det, _ = m(x)
+        assert bool(torch.isfinite(det).all())
+        flat = det.cpu().numpy().reshape(-1, det.shape[-1])
+        got, ref = flat[S[f"{name}.rows"]], S[f"{name}.det_rows"]
+        conf = ref[:, 4] > 0.25
+        cls = float((got[conf, 5:].argmax(-1) == ref[conf, 5:].argmax(-1)).mean())
+        ri = row_iou(got, ref, conf)
+        out[prec] = dict(cls=cls, row_iou=float(ri.mean()), row50=float((ri > 0.5).mean()), dobj=float(np.abs(got[:, 4] - ref[:, 4]).mean()), rows=int(conf.sum()))
+        record_agreement(f"{name} {prec} vs reference rows (fp8 file)", cls_agree=cls, row_iou_mean=float(ri.mean()), row_iou_gt50=float((ri > 0.5).mean()),
+                         mean_dobj=out[prec]["dobj"], confident_rows=int(conf.sum()))
+    f = out["fp8"]
+    lo = FP8_REF_FLOORS[name]
+    assert f["rows"] > 20
+    assert f["cls"] >= lo["cls"] and f["row_iou"] >= lo["row_iou"] and f["row50"] >= lo["row50"] and f["dobj"] <= lo["dobj"], (out, lo)
+
+
+# 0.9 x the round-3 measurements (objectness error: 1.1 x)
+FP8_REF_FLOORS = {   # measured (profiles/r03_parity_margins.json): cls / row IoU / rows with IoU > 0.5 / mean |d obj|
+    "s_1280": dict(cls=0.758, row_iou=0.588, row50=0.689, dobj=0.046),      # 0.843 / 0.654 / 0.766 / 0.0418 (bf16: 0.986 / 0.954 / 0.995 / 0.0031)
+    "l_640": dict(cls=0.669, row_iou=0.348, row50=0.321, dobj=0.068),       # 0.744 / 0.387 / 0.357 / 0.0617 (bf16: 0.972 / 0.864 / 0.950 / 0.0055)
+    "l_1280": dict(cls=0.711, row_iou=0.367, row50=0.347, dobj=0.066),      # 0.790 / 0.408 / 0.386 / 0.0598 (bf16: 0.975 / 0.879 / 0.962 / 0.0050)
+}
+
+
+def test_fp8_config5_shard_b32_1536_deterministic_and_batch_independent():
+    """BASELINE.json configs[4], one GPU's shard at its own size: skyeye_l fp8, B = 32 frames of 1536 x 1536 (145 152 rows each):
+    two runs bit-identical, frames of the batch equal the same frames run alone (as a batch of 2), all values finite, probabilities in
+    [0, 1]; the post-NMS boxes of both runs are identical too."""
+    from skyeye.utils.metrics import nms_raw
+    m = _detector("skyeye_l", "fp8")
+    x = torch.from_numpy(seeded_scene(32, 1536, 1536, 9)).cuda()
+    m.calibrate(x[:16])
+    a, _ = m(x, return_raw=False)
+    ra, ca = nms_raw(a, 0.25, 0.45)
+    a = a.clone()
+    b, _ = m(x, return_raw=False)
+    assert a.shape == (32, 145152, 15)
+    assert bool(torch.isfinite(a).all())
+    assert torch.equal(a, b), f"two runs differ in {int((a != b).sum())} values"
+    rb, cb = nms_raw(b, 0.25, 0.45)
+    assert torch.equal(ca, cb) and torch.equal(ra, rb)
+    pair, _ = m(x[30:], return_raw=False)
+    assert torch.equal(pair[0], a[30]) and torch.equal(pair[1], a[31]), "frames 30 / 31 of the batch differ from the same frames run as a batch of 2"
+    assert float(a[..., 4:].min()) >= 0.0 and float(a[..., 4:].max()) <= 1.0
 
 
 def test_fp8_full_size_1536_deterministic_and_batch_independent():
