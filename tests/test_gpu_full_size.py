@@ -116,7 +116,8 @@ def test_bf16_vs_fp32_engine_post_nms_at_b32_1280():
     m50, m90, miou = float(np.mean([r[0] for r in r50])), float(np.mean([r[0] for r in r90])), float(np.mean([r[1] for r in r50]))
     record_agreement("skyeye_s B=32 @1280 bf16 vs fp32 engine (post-NMS)", boxes_ref=n_ref, matched_iou50=m50, matched_iou90=m90, mean_iou=miou)
     assert n_ref > 500
-    assert m50 > 0.85 and miou > 0.9, (m50, m90, miou)
+    # measured (r02 / r03, bit-identical kernels): 0.93 of the fp32 engine's boxes matched at IoU 0.5, 0.81 at IoU 0.9, mean IoU 0.93
+    assert m50 > 0.88 and m90 > 0.73 and miou > 0.9, (m50, m90, miou)
 
 
 def test_views_of_2gib_and_more_run_as_batch_slices():
