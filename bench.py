@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--with-raw", action="store_true", help="also write the three raw detection levels (the reference's second return value)")
+    ap.add_argument("--streams", type=int, default=2, help="run the batch as this many equal slices on parallel branches of the captured graph (each "
+                    "slice has its own plan); 1 = the whole batch through one plan")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 (shard), 5 (shard) behind the headline measurement")
     return ap.parse_args()
 
@@ -186,6 +188,9 @@ def main():
         calibrate_objectness(model, x, 0.01, a.conf)
         model.reuse_output_buffers(True)
 
+        if a.streams > 1 and precision != "fp8":
+            model.parallel_slices(a.streams)                     # the batch as equal slices on parallel HIP streams, one plan each
+
         def local_step():
             det, _raw = model(x, return_raw=a.with_raw)                             # detector.py:300-324
             return nms_raw(det, a.conf, a.iou, max_detections=300)                  # metrics.py:361-457, no host sync
@@ -276,7 +281,8 @@ def main():
                                + (" -> RCCL all-gather of boxes" if world > 1 else ""),
                    "global_batch": world * B, "frames_per_gpu": B, "image_size": S, "candidates_target": "1% > conf",
                    "mean_boxes_kept_per_image": round(kept_mean, 1), "parallelism": f"dp{world} (independent images)",
-                   "hip_graph": graph is not None, "raw_levels_written": bool(a.with_raw)},
+                   "hip_graph": graph is not None, "raw_levels_written": bool(a.with_raw),
+                   "batch_slices_on_parallel_streams": a.streams if a.precision != "fp8" else 1},
     }
 
     if rank == 0 and not a.no_roofline:

@@ -354,6 +354,18 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
         auto wfrag = [&](int st, int kk, int sp, int h) -> u32x4_t {
             return *reinterpret_cast<const u32x4_t*>(ring + (st & (NST - 1)) * SLAB + (4 * hc + 2 * sp + h) * 2048 + (kk ? arow ^ 64 : arow));
         };
+        // The DMA requests of a step (its weight slab, then the x pieces of the next tile) do not go out at the head of the step,
+        // where all eight waves would issue theirs at once (measured ~150 cycles per piece there), and not at the same point in
+        // both waves of a SIMD (waves w and w + 4): waves 4..7 issue behind the first MFMA group, waves 0..3 behind the second, so
+        // that one wave's issue stalls run under the other's matrix work.
+        auto step_dma = [&](int st) {
+            constexpr int XS0d = NCH + 9;
+            if (st + 3 < NSTEP) issue_slab(st + 3);
+            else if (has_next) issue_slab(st + 3 - NSTEP);
+            const int k = st - XS0d;
+            const int nx = k < 0 ? 0 : (k * 2 + 2 <= XDMA ? 2 : (k * 2 < XDMA ? XDMA - k * 2 : 0));
+            if (nx > 0 && has_next && wave < 4) issue_x(nb, ny0, nx0, 0, k * 2, k * 2 + nx);
+        };
 #pragma unroll
         for (int s = NCH; s < NSTEP; ++s) {
             const int p = s & 1;
@@ -385,6 +397,7 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
                 for (int i = 0; i < 4; ++i)
                     if (!(BK_DBG(a) & 4)) S1<__bf16>::mma(wq01[p][0][h], pf0[p][i], acc[h][i]);
             if (s == 6) BK_STAMP(29);
+            if (wave >= 4) step_dma(s);
 #pragma unroll
             for (int h = 0; h < 2; ++h) wq3[h] = wfrag(s, 1, 1, h);
             __builtin_amdgcn_sched_barrier(0);
@@ -394,11 +407,7 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
                 for (int i = 0; i < 4; ++i)
                     if (!(BK_DBG(a) & 4)) S1<__bf16>::mma(wq01[p][1][h], pf0[p][i], acc[2 + h][i]);
             if (s == 6) BK_STAMP(30);
-            // the DMA requests of the step sit behind its first two MFMA groups: at the head of the step all eight waves would
-            // issue theirs at once (measured ~150 cycles per piece there), here they go out under the other wave's matrix work
-            if (s + 3 < NSTEP) issue_slab(s + 3);
-            else if (has_next) issue_slab(s + 3 - NSTEP);
-            if (NX(s) > 0 && has_next && wave < 4) issue_x(nb, ny0, nx0, 0, (s - XS0) * 2, (s - XS0) * 2 + NX(s));
+            if (wave < 4) step_dma(s);
             if (s + 1 < NSTEP) {                              // K-step 0 pixels of the next tap
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pf0[p ^ 1][i] = tap_frag(s + 1, i, 0);

@@ -1,0 +1,53 @@
+"""``parallel_slices``: a batch run as equal slices on parallel HIP streams (one plan per slice, the slices write into ONE output
+tensor) is bit-identical to the whole-batch call -- frames are independent units --, also under capture_graph and with the raw
+levels skipped."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_detector, detector_params, variant_cfg
+from seeded import seeded_scene
+from skyeye.utils.metrics import nms_raw
+from skyeye.utils.torch_utils import capture_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(prec="bf16"):
+    m = build_detector(variant_cfg("skyeye_s"))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in detector_params("skyeye_s").items()}, strict=True)
+    return m.eval().set_precision(prec)
+
+
+@pytest.mark.parametrize("nsl,B,hw", [(2, 8, (320, 320)), (4, 8, (256, 384)), (2, 32, (640, 640))])
+def test_sliced_batch_equals_whole_batch(nsl, B, hw):
+    x = torch.from_numpy(seeded_scene(B, hw[0], hw[1], 31)).cuda()
+    whole = _model()
+    det0, raw0 = whole(x)
+    sl = _model().parallel_slices(nsl)
+    det1, raw1 = sl(x)
+    assert torch.equal(det0, det1)
+    assert all(torch.equal(a, b) for a, b in zip(raw0, raw1))
+    det2, raw2 = sl(x, return_raw=False)
+    assert raw2 == [] and torch.equal(det0, det2)
+    det3, _ = sl(x[:3])                       # a batch the slices do not divide: the whole-batch plan
+    assert torch.equal(det3, det0[:3])
+
+
+def test_sliced_batch_in_a_captured_graph():
+    x = torch.from_numpy(seeded_scene(8, 320, 320, 32)).cuda()
+    ref = _model()
+    d0, _ = ref(x, return_raw=False)
+    r0, c0 = nms_raw(d0, 0.25, 0.45)
+    m = _model().parallel_slices(2).reuse_output_buffers(True)
+
+    def step():
+        d, _ = m(x, return_raw=False)
+        return nms_raw(d, 0.25, 0.45)
+
+    graph, (rows, counts) = capture_graph(step, warmup=2)
+    for _ in range(3):
+        rows.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(counts, c0) and torch.equal(rows, r0)
