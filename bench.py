@@ -117,6 +117,7 @@ def calibrate_objectness(model, x, target=0.01, conf=0.25):
 FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded by launch_conv)
     ("halo3x3", "conv_halo_kernel: 3x3 halo tile + weight ring (stride 1 and 2)", lambda v: 4000 <= v < 5000 or 6000 <= v < 7000),
     ("halo_narrow", "conv_halo_small_kernel: stem / narrow-input 3x3, K resident", lambda v: 5000 <= v < 6000),
+    ("bneck128", "bneck128_kernel: BottleneckBlock(128, 128) 1x1 -> 3x3 (+residual) in one kernel, 4-stage weight ring", lambda v: v == 7128),
     ("halo_cv1", "conv_halo_kernel<CV1>: bottleneck 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
     ("stem_down", "stem_down_kernel: frames -> FocusBlock 3x3 -> 3x3 stride 2 in one kernel", lambda v: 8000 <= v < 8500),
     ("csp_stage", "csp_stage_kernel: CSPBlock(64, 64, 1) = cv1|cv2 -> 1x1 -> 3x3 + shortcut -> cv3 in one kernel", lambda v: 8500 <= v < 9000),
@@ -304,12 +305,13 @@ def main():
                     e["variants"].add(tag % 10000)
                 last = name
         peak = PEAK_TFLOPS[a.precision]
-        pmc, pmc_src = {}, None
+        pmc, pmc_src, pmc_lib = {}, None, None
         if a.model == "skyeye_s" and B == 32 and S == 1280 and a.precision == "bf16":
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):     # latest PMC pass (tools/pmc_traffic.sh)
                 try:
-                    pmc, pmc_src = json.load(open(f))["by_variant"], os.path.relpath(f, ROOT)
+                    pj = json.load(open(f))
+                    pmc, pmc_src, pmc_lib = pj["by_variant"], os.path.relpath(f, ROOT), pj.get("library_sources")
                 except Exception:  # noqa: BLE001
                     pass
         table = {}
@@ -334,6 +336,8 @@ def main():
             "definition": "end-to-end: frames/s per GPU x algorithmic GFLOP/frame (2*MAC over conv/linear) / dense MFMA peak",
             "traffic": round(sum(v["pmc_bytes_per_launch"] * v["launches"] for v in table.values() if v["pmc_bytes_per_launch"])) or None,
             "traffic_source": pmc_src, "traffic_note": "PMC bytes per step summed over the convolution families (FETCH_SIZE x2 + WRITE_SIZE)",
+            # the PMC pass is a separate, committed run: stale as soon as a kernel changes -- say so instead of quoting it silently
+            "traffic_measured_on_this_build": (pmc_lib == N.build_info()) if pmc_src else None,
             "graph_gflop_per_frame": round(graph_flops / B / 1e9, 2), "baseline_gflop_per_frame": GFLOP_PER_FRAME.get((a.model, S)),
             "algorithmic_bytes_per_step": round(graph_bytes), "end_to_end_hbm_gbps": round(fps / world / B * graph_bytes / 1e9, 1),
             "end_to_end_frac_hbm": round(fps / world / B * graph_bytes / 1e9 / PEAK_HBM_GBPS, 4),

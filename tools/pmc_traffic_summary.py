@@ -32,6 +32,8 @@ for k, v in agg.items():
         variant = 8064
     elif "csp_stage_kernel" in k:
         variant = 8564
+    elif "bneck128_kernel" in k:
+        variant = 7128
     elif "head_stream_kernel" in k:
         variant = 1548
     elif "conv_halo_kernel" in k:
@@ -56,6 +58,19 @@ for v in out.values():
 for v in by_variant.values():
     v["hbm_bytes_per_launch"] = v["hbm_bytes"] / v["launches"]
 total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values())
+def _library_sources():
+    """Hash of the kernel sources the measured library was built from (bench.py compares it with the running library's)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "skyeye-aerial-object-detection-using-yolo_amd"))
+    try:
+        from skyeye import _native
+        return _native.build_info()
+    except Exception:  # noqa: BLE001
+        return None
+
+
 print(json.dumps(dict(note="FETCH_SIZE*2 + WRITE_SIZE, KB -> bytes; bench.py --steps 2 --warmup 1 --no-graph (+ calibration forwards of 2 frames, + the timing-bucket passes of bench.py)",
+                      library_sources=_library_sources(),
                       total_hbm_bytes_all_kernels=total,
                       by_variant=by_variant, kernels=out), indent=1))
