@@ -193,8 +193,10 @@ def main():
             model.parallel_slices(a.streams)                     # the batch as equal slices on parallel HIP streams, one plan each
 
         def local_step():
-            det, _raw = model(x, return_raw=a.with_raw)                             # detector.py:300-324
-            return nms_raw(det, a.conf, a.iou, max_detections=300)                  # metrics.py:361-457, no host sync
+            if a.with_raw or a.streams <= 1:
+                det, _raw = model(x, return_raw=a.with_raw)                         # detector.py:300-324
+                return nms_raw(det, a.conf, a.iou, max_detections=300)              # metrics.py:361-457, no host sync
+            return model.detect_nms(x, a.conf, a.iou, max_detections=300)           # the same pair; each slice's NMS on its own stream
 
         graph = None
         if not a.no_graph:

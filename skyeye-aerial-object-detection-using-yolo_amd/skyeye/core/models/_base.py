@@ -342,8 +342,9 @@ class NativeModule(nn.Module):
             return False                # every slice would calibrate itself on its own frames: other scales than the whole batch
         return True
 
-    def _run_sliced(self, inputs, extra_cfg, skip, nsl):
-        """``parallel_slices``: slice i of the batch through plan slot i on side stream i, into rows [i b, (i + 1) b) of the outputs."""
+    def _run_sliced(self, inputs, extra_cfg, skip, nsl, post=None):
+        """``parallel_slices``: slice i of the batch through plan slot i on side stream i, into rows [i b, (i + 1) b) of the outputs.
+        ``post(i, lo, hi, out_views)``: more work of slice i (its NMS) enqueued on its stream before the join."""
         dev = inputs[0].device
         B = inputs[0].shape[0]
         b = B // nsl
@@ -368,6 +369,8 @@ class NativeModule(nn.Module):
                 ents[i][1].forward([N.buffer_from_tensor(t) for t in parts[i]],
                                    [N.null_buffer() if o is None else N.buffer_from_tensor(o[i * b:(i + 1) * b]) for o in outs],
                                    streams[i].cuda_stream)
+                if post is not None:
+                    post(i, i * b, (i + 1) * b, [None if o is None else o[i * b:(i + 1) * b] for o in outs])
         for s_ in streams:
             cur.wait_stream(s_)                                                 # join: the caller's stream owns the results again
         return list(outs)

@@ -178,6 +178,36 @@ class SkyEyeDetector(NativeModule):
             return outs[0], outs[1:]
         return outs[1:]
 
+    def detect_nms(self, x, conf_threshold=0.25, iou_threshold=0.45, max_detections=300, **nms_kw):
+        """forward (raw levels not written) + non_max_suppression in one asynchronous call -> (rows [B, max_det, 7], counts [B]) on the
+        device, the ``skyeye.utils.metrics.nms_raw`` result of ``self(x)[0]`` (validate.py:245-255 / detect.py:140-145 do exactly this
+        pair).  An extension: with ``parallel_slices`` the NMS of a slice is enqueued on that slice's stream, so it runs beside the
+        other slice's convolutions instead of behind the join."""
+        from ...utils.metrics import nms_raw
+        if self.training:
+            raise RuntimeError("detect_nms is an eval-mode call")
+        xi = self._prepare_input(x)
+        nsl = self.__dict__.get("_slices", 1)
+        if nsl > 1 and self._sliceable([xi], nsl):
+            B = xi.shape[0]
+            cache = self._out_cache
+            ck = ("nms", B, int(max_detections))
+            bufs = cache.get(ck) if cache is not None else None
+            if bufs is None:
+                bufs = (torch.empty((B, int(max_detections), 7), dtype=torch.float32, device=xi.device),
+                        torch.empty((B,), dtype=torch.int32, device=xi.device))
+                if cache is not None:
+                    cache[ck] = bufs
+            rows, counts = bufs
+
+            def post(i, lo, hi, views):
+                nms_raw(views[0], conf_threshold, iou_threshold, max_detections=max_detections, out=rows[lo:hi], counts=counts[lo:hi], **nms_kw)
+
+            self._run_sliced([xi], None, (1, 2, 3), nsl, post=post)
+            return rows, counts
+        det = self._run([xi], skip=(1, 2, 3))[0]
+        return nms_raw(det, conf_threshold, iou_threshold, max_detections=max_detections, **nms_kw)
+
     def warmup(self, imgsz=(1, 3, 640, 640)):
         """detect.py:126 calls model.warmup(imgsz=...)."""
         dev = next(self.parameters()).device

@@ -45,8 +45,9 @@ def forget_stream(device_index, stream):
 
 
 def nms_raw(prediction, conf_threshold=0.25, iou_threshold=0.45, classes=None, agnostic=False, multi_label=False,
-            max_detections=300, mode="literal", max_nms=30000, max_wh=4096.0):
-    """Asynchronous form: returns (rows [B, max_det, 7] float32, counts [B] int32) on the device, no host sync."""
+            max_detections=300, mode="literal", max_nms=30000, max_wh=4096.0, out=None, counts=None):
+    """Asynchronous form: returns (rows [B, max_det, 7] float32, counts [B] int32) on the device, no host sync.  ``out`` / ``counts``:
+    contiguous tensors (or batch slices of them) to write into instead of fresh ones."""
     if not prediction.is_cuda:
         raise N.SkyEyeNativeError("non_max_suppression: prediction must be on the HIP device (no CPU path)")
     pred = prediction.float().contiguous()
@@ -62,8 +63,13 @@ def nms_raw(prediction, conf_threshold=0.25, iou_threshold=0.45, classes=None, a
     for i, c in enumerate(cls):
         p.classes[i] = c
     # the kernel defines every element (rows past the count are zeroed, k_nms.hip: nms_greedy_kernel): no fill launches here
-    out = torch.empty((B, max_detections, 7), dtype=torch.float32, device=pred.device)
-    counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
+    if out is None:
+        out = torch.empty((B, max_detections, 7), dtype=torch.float32, device=pred.device)
+    if counts is None:
+        counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
+    if tuple(out.shape) != (B, max_detections, 7) or out.dtype != torch.float32 or not out.is_contiguous() or \
+            tuple(counts.shape) != (B,) or counts.dtype != torch.int32 or not counts.is_contiguous():
+        raise N.SkyEyeNativeError("nms_raw: out must be a contiguous float32 [B, max_detections, 7] and counts a contiguous int32 [B]")
     stream = torch.cuda.current_stream(pred.device).cuda_stream
     h = _handle(pred.device.index or 0, stream)
     N.check(h.L.sky_nms(h.h, pred.data_ptr(), B, Nrows, no - 5, ctypes.byref(p), out.data_ptr(), counts.data_ptr(),

@@ -51,3 +51,19 @@ def test_sliced_batch_in_a_captured_graph():
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(counts, c0) and torch.equal(rows, r0)
+
+
+def test_detect_nms_equals_forward_then_nms():
+    x = torch.from_numpy(seeded_scene(8, 320, 320, 33)).cuda()
+    ref = _model()
+    d0, _ = ref(x, return_raw=False)
+    r0, c0 = nms_raw(d0, 0.2, 0.45)
+    r1, c1 = ref.detect_nms(x, 0.2, 0.45)
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+    m = _model().parallel_slices(2).reuse_output_buffers(True)
+    graph, (rows, counts) = capture_graph(lambda: m.detect_nms(x, 0.2, 0.45), warmup=2)
+    rows.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(counts, c0) and torch.equal(rows, r0)
+    assert int(c0.max()) > 0
