@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         u32x4_t pf0[2][4];                                    // [step parity]: pixel fragments of K-step 0
+        u32x4_t pf1[4], wq2[2], wq3[2];                       // K-step 1 pixel fragments, weight pairs of K-step 1
         int pb[13];                                           // (per tile: 40 instructions, and the registers are free during cv1)
         {
             int frt = fr;
@@ -384,7 +385,6 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pf0[p][i] = tap_frag(s, i, 0);
             }
-            u32x4_t pf1[4], wq2[2], wq3[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pf1[i] = tap_frag(s, i, 1);
 #pragma unroll
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
                     if (!(BK_DBG(a) & 4)) S1<__bf16>::mma(wq01[p][1][h], pf0[p][i], acc[2 + h][i]);
             if (s == 6) BK_STAMP(30);
             if (wave < 4) step_dma(s);
-            if (s + 1 < NSTEP) {                              // K-step 0 pixels of the next tap
+            if (s + 1 < NSTEP) {                        // K-step 0 pixels of the next tap
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pf0[p ^ 1][i] = tap_frag(s + 1, i, 0);
             }
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
                 for (int i = 0; i < 4; ++i)
                     if (!(BK_DBG(a) & 4)) S1<__bf16>::mma(wq2[h], pf1[i], acc[h][i]);
             if (s == 6) BK_STAMP(31);
-            if (s + 1 < NSTEP) {                              // K-step 0 weight pairs of the next slab
+            if (s + 1 < NSTEP) {                        // K-step 0 weight pairs of the next slab
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
