@@ -395,6 +395,8 @@ def main():
                 del lg
                 torch.cuda.empty_cache()
             except Exception as ex:  # noqa: BLE001 -- a failing side leg must not lose the headline line
+                if world > 1:
+                    raise                       # (a rank that skipped a leg would leave the others waiting in its collectives)
                 others.append({"workload": f"{name} {prec} @{size}", "error": str(ex)[:300]})
         out["other_configs"] = others
     if world > 1:
