@@ -115,6 +115,7 @@ def calibrate_objectness(model, x, target=0.01, conf=0.25):
 
 
 FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded by launch_conv)
+    ("deep3x3", "conv3x3_deep_kernel: 3x3 stride 1, Cin >= 256: two halo images, 4-stage weight ring, counted waits", lambda v: 4600 <= v < 4800),
     ("halo3x3", "conv_halo_kernel: 3x3 halo tile + weight ring (stride 1 and 2)", lambda v: 4000 <= v < 5000 or 6000 <= v < 7000),
     ("halo_narrow", "conv_halo_small_kernel: stem / narrow-input 3x3, K resident", lambda v: 5000 <= v < 6000),
     ("bneck128", "bneck128_kernel: BottleneckBlock(128, 128) 1x1 -> 3x3 (+residual) in one kernel, 4-stage weight ring", lambda v: v == 7128),

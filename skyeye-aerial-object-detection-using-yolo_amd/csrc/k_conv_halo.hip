@@ -1216,6 +1216,11 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
         if (e2 == hipSuccess && variant) *variant = 6000 + (a.Cout == 32 ? 32 : 64);
         return e2;
     }
+    if (!small && a.stride == 1 && conv3x3_deep_ok(dtype, a)) {      // wide inputs: the deep-pipelined kernel (k_conv3x3_deep.hip)
+        const hipError_t ed = launch_conv3x3_deep(dtype, a, s);
+        if (ed == hipSuccess && variant) *variant = 4600 + 128;
+        return ed;
+    }
     if (!small && (a.src_mode || cb % 128 != 0 || a.Cout % 64 != 0)) return hipErrorNotSupported;
     if ((long)a.Kpad * esz < 9L * a.Cin * esz) return hipErrorNotSupported;
     if ((long)a.Cout * a.Kpad * esz >= (1L << 31)) return hipErrorNotSupported;

@@ -36,6 +36,7 @@ enum PlanOpt : unsigned {
     OPT_NO_HEAD_STREAM = 1u << 21,   // SKY_NO_HEAD_STREAM   detection levels on the implicit-GEMM tile kernel (default: the streaming head kernel)
     OPT_HEAD_STREAM_FORCE = 1u << 22,// SKY_HEAD_STREAM=force the streaming head kernel on small levels too (default: only where 32-pixel steps fill the device)
     OPT_NO_BNECK128 = 1u << 23,      // SKY_NO_BNECK128      128-channel bottlenecks as two launches (default: one kernel, k_bneck.hip)
+    OPT_NO_DEEP3X3 = 1u << 24,       // SKY_NO_DEEP3X3       wide 3x3 stride-1 layers on the halo-tile kernel (default: k_conv3x3_deep.hip where covered)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -183,6 +184,10 @@ hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 // BottleneckBlock(128, 128) as one kernel (k_bneck.hip; bf16): ConvArgs of the 3x3 with c1_w / c1_bias / c1_Kpad / c1_res set
 bool bneck128_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck128(const ConvArgs& a, hipStream_t s);
+
+// deep-pipelined 3x3 stride 1 for Cin a multiple of 256 (k_conv3x3_deep.hip; bf16): variant 4600 + 128
+bool conv3x3_deep_ok(int dtype, const ConvArgs& a);
+hipError_t launch_conv3x3_deep(int dtype, const ConvArgs& a, hipStream_t s);
 
 bool csp_stage_supported(const CspStageArgs& a);
 hipError_t launch_csp_stage(const CspStageArgs& a, hipStream_t s);

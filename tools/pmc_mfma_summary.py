@@ -21,6 +21,8 @@ def family(k):
         return "csp_stage"
     if "bneck128_kernel" in k:
         return "bneck128"
+    if "conv3x3_deep_kernel" in k:
+        return "deep3x3"
     if "head_stream_kernel" in k:
         return "tile"                # detection levels: same family as the tile kernel's head launches
     if "conv_halo_kernel" in k and (re.search(r"Lb1EEEvNS_8ConvArgsE$", k.split("(")[0]) or re.search(r", true>$", k.split("(")[0])):

@@ -34,6 +34,8 @@ for k, v in agg.items():
         variant = 8564
     elif "bneck128_kernel" in k:
         variant = 7128
+    elif "conv3x3_deep_kernel" in k:
+        variant = 4728
     elif "head_stream_kernel" in k:
         variant = 1548
     elif "conv_halo_kernel" in k:
