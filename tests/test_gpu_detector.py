@@ -145,7 +145,11 @@ def test_detector_bf16_against_sampled_reference_fixture(case):
     record_agreement(f"{name} bf16 vs reference rows", cls_agree=cls, row_iou_mean=float(ri.mean()), row_iou_gt50=float((ri > 0.5).mean()),
                      mean_dobj=dobj, logit_err_of_range=logit_err, confident_rows=int(conf.sum()))
     assert np.isfinite(det).all()
-    assert cls > 0.93 and float(ri.mean()) > 0.8 and float((ri > 0.5).mean()) > 0.92 and dobj < 0.01 and logit_err < 0.1, (cls, ri.mean(), dobj, logit_err)
+    # floors per case: 0.97 x the measured class agreement / row IoU (round 3, profiles/r03_parity_margins.json), objectness and logit
+    # errors 1.5 x measured
+    lo = {"s_640": (0.955, 0.92, 0.964, 0.0056, 0.056), "s_1280": (0.956, 0.925, 0.965, 0.0047, 0.057), "l_640": (0.942, 0.838, 0.921, 0.0083, 0.072),
+          "l_1280": (0.946, 0.852, 0.933, 0.0075, 0.091), "ha_s_1280": (0.96, 0.935, 0.968, 0.0062, 0.047)}.get(name, (0.93, 0.8, 0.92, 0.01, 0.1))
+    assert cls > lo[0] and float(ri.mean()) > lo[1] and float((ri > 0.5).mean()) > lo[2] and dobj < lo[3] and logit_err < lo[4], (cls, ri.mean(), dobj, logit_err, lo)
 
 
 def test_train_mode_returns_raw_only():
