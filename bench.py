@@ -370,7 +370,26 @@ def main():
             d, _ = O.detector_forward(Pc, frames_np[i % B:i % B + 1].astype(np.float32) / np.float32(255.0), nc, **okw)
             O.non_max_suppression(d, a.conf, a.iou)
         cpu_dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(n / cpu_dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port",
+        # second comparator (optional): the same graph in torch.nn.functional on the host cores (tests/torch_graph.py:
+        # checker code, plain variants only), one frame, bounded to a few seconds
+        torch_cmp = None
+        if not okw["enhanced"] and not okw["head_attention"]:
+            try:
+                import torch_graph as TG
+                nt = torch.get_num_threads()
+                Pt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in Pc.items() if np.asarray(v).dtype != np.int64}
+                xt = torch.from_numpy(frames_np[:1].astype(np.float32) / np.float32(255.0))
+                TG.detector_forward(Pt, xt, nc)
+                t1 = time.perf_counter()
+                reps = 0
+                while reps < 4 and time.perf_counter() - t1 < 6.0:
+                    TG.detector_forward(Pt, xt, nc)
+                    reps += 1
+                torch_cmp = {"value": round(reps / (time.perf_counter() - t1), 4), "unit": "frames/s", "threads": nt,
+                             "what": "the same graph in torch.nn.functional on the CPU (forward + decode, no NMS), the build's own code"}
+            except Exception as ex:  # noqa: BLE001
+                torch_cmp = {"error": str(ex)[:200]}
+        out["cpu_baseline"] = {"value": round(n / cpu_dt, 4), "unit": "frames/s", "cores": O.threads(), "kind": "port", "torch_graph": torch_cmp,
                                "sample": f"{n} frame(s) of the same workload ({a.model} fp32 @{S}x{S}, forward+decode+NMS), "
                                          f"oracle/ C+OpenMP port of the reference path, {O.threads()} threads used of {os.cpu_count()} host "
                                          "CPUs visible; the reference's own PyTorch-CPU path measured ~1.09 frames/s on 8 cores at "
