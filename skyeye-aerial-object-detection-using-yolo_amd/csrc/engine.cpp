@@ -105,7 +105,8 @@ struct Op {
     int heads = 0, ntok = 0, nW = 0, mask_ext = -1, v_off = 0, force_nhwc = 0;
     int win = 0;           // attention over the win x win windows of the input map (0: over all H*W tokens of each image)
     float scale = 1.0f, r2 = 1.0f;
-    TV in2;                // second activation input (CLA key/value tensor)
+    TV in2;                // second activation input (CLA key/value tensor; 1x1 convolution: the first in2_cin channels of K, ConvArgs::in2)
+    int in2_cin = 0, in2_up2 = 0;
 };
 
 struct DevConv {
@@ -517,8 +518,10 @@ static TV bottleneck(Ctx& c, const std::string& p, const TV& x, int cin, int cou
 }
 
 // CSPBlock (blocks.py:93-123): cv3(cat(bottlenecks(cv1(x)), cv2(x)))
+// up_src: the first up_src->C channels of x are cat's "2x-upsampled lateral map" half (detector.py:215,219): the fused cv1 | cv2 GEMM -- the
+// only reader of x -- takes them from the small map itself (ConvArgs::in2), that half of x is never written
 static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int n, bool shortcut, float expansion,
-              const TV* out_into = nullptr, int out_dt = -1)
+              const TV* out_into = nullptr, int out_dt = -1, const TV* up_src = nullptr)
 {
     const int h = (int)(cout * expansion);
     c.need(p + "cv1.conv.weight", {h, cin, 1, 1});
@@ -533,6 +536,10 @@ static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int 
         Op op;
         op.kind = OP_CONV;
         op.in = x; op.out = cat;
+        if (up_src) {
+            op.in = Ctx::slice(x, up_src->C, x.C - up_src->C);
+            op.in2 = *up_src; op.in2_cin = up_src->C; op.in2_up2 = 1;
+        }
         op.cin = cin; op.cout = 2 * h; op.ks = 1; op.stride = 1; op.act = ACT_SILU;
         op.Ho = x.H; op.Wo = x.W;
         op.cdt = x.dt;
@@ -949,7 +956,29 @@ static NeckSlots neck_alloc(Ctx& c, int B, int H3, int W3, int H4, int W4, int H
 static void neck(Ctx& c, const std::string& p, const NeckSlots& n, int c3, int c4, int c5, TV out[3])
 {
     const TV &p3 = n.p3, &p4 = n.p4, &p5 = n.p5;
-    auto lateral = [&](const std::string& name, const TV& x, int cin, int cout, const TV& slot, int Ht, int Wt) {
+    // would the CSP's fused cv1 | cv2 GEMM read the upsampled half of its input from the small lateral map itself (conv_accepts_in2)?
+    auto reads_small = [&](const TV& cat, int c_lat, int hidden2) {
+        if (!c.emit || (c.e.dtype != SKY_BF16 && c.e.dtype != SKY_F32) || (c.e.opts & OPT_NO_IN2)) return false;
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        const int esz = dtype_size(c.e.dtype);
+        a.B = cat.B; a.H = cat.H; a.W = cat.W; a.Ho = cat.H; a.Wo = cat.W; a.Cin = cat.C; a.Cout = hidden2; a.ldi = cat.ld; a.ldo = hidden2;
+        a.ks = 1; a.stride = 1; a.act = ACT_SILU; a.M = cat.B * cat.H * cat.W; a.out_dt = -1;
+        a.Kpad = (cat.C + conv_k_step(c.e.dtype) - 1) / conv_k_step(c.e.dtype) * conv_k_step(c.e.dtype);
+        a.opts = c.e.opts; a.device = c.e.cfg.device; a.n_cu = c.e.n_cu;
+        a.in2 = &a; a.in2_cin = c_lat; a.ldi2 = c_lat; a.in2_up2 = 1;
+        const double ext = ((double)a.M - 1.0) * cat.ld * esz + (double)cat.C * esz;
+        a.in_bytes = a.in2_bytes = a.out_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;
+        return conv_accepts_in2(c.e.dtype, a);
+    };
+    // returns the small lateral map when the consumer reads it directly (then the slot's half of the concat buffer stays unwritten)
+    auto lateral = [&](const std::string& name, const TV& x, int cin, int cout, const TV& cat, int Ht, int Wt, int hidden2, TV& small) {
+        const TV slot = Ctx::slice(cat, 0, cout);
+        if (Ht == 2 * x.H && Wt == 2 * x.W && reads_small(cat, cout, hidden2)) {
+            small = conv_block(c, p + name, x, cin, cout, 1, 1, true);
+            c.tie_scales(small.buf, cat.buf);
+            return true;
+        }
         if (Ht == 2 * x.H && Wt == 2 * x.W) {   // exact 2x: upsample in the epilogue
             ConvOpt o;
             o.out_into = &slot; o.up2 = true;
@@ -961,15 +990,17 @@ static void neck(Ctx& c, const std::string& p, const NeckSlots& n, int c3, int c
             c.tie_scales(t.buf, slot.buf);
             c.push(u);
         }
+        return false;
     };
-    lateral("lateral_conv5.", p5, c5, c4, Ctx::slice(n.cat_p4m, 0, c4), p4.H, p4.W);   // :210,214
-    lateral("lateral_conv4.", p4, c4, c3, Ctx::slice(n.cat_p3m, 0, c3), p3.H, p3.W);   // :211,218
+    TV small5, small4;
+    const bool s5 = lateral("lateral_conv5.", p5, c5, c4, n.cat_p4m, p4.H, p4.W, c4, small5);   // :210,214
+    const bool s4 = lateral("lateral_conv4.", p4, c4, c3, n.cat_p3m, p3.H, p3.W, c3, small4);   // :211,218
     TV p4p_slot = Ctx::slice(n.cat_p4c, c3, c4);
-    csp(c, p + "fpn_conv4.", n.cat_p4m, 2 * c4, c4, 3, true, 0.5f, &p4p_slot);          // :216
+    csp(c, p + "fpn_conv4.", n.cat_p4m, 2 * c4, c4, 3, true, 0.5f, &p4p_slot, -1, s5 ? &small5 : nullptr);          // :216
     // fp8 engine: the three maps the detection levels read stay bf16 (the last rounding before the box regression is bf16's, and
     // the detection convolutions then run in bf16 like the stem); the stride-2 convolutions that also read them write fp8 again
     const int odt = c.e.dtype == SKY_FP8 ? (int)SKY_BF16 : -1;
-    out[0] = csp(c, p + "fpn_conv3.", n.cat_p3m, 2 * c3, c3, 3, true, 0.5f, nullptr, odt);            // :220
+    out[0] = csp(c, p + "fpn_conv3.", n.cat_p3m, 2 * c3, c3, 3, true, 0.5f, nullptr, odt, s4 ? &small4 : nullptr);            // :220
     ConvOpt d3;
     TV d3_slot = Ctx::slice(n.cat_p4c, 0, c3);
     d3.out_into = &d3_slot;
@@ -1458,6 +1489,12 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                     const double fext = (((double)a.M - 1.0) * f.out.ld + f.cout) * dtype_size(f.out.dt);
                     a.f2_out_bytes = fext < 2147483000.0 ? (unsigned)fext : 0u;
                 }
+                if (op.in2.valid() && op.in2_cin > 0) {
+                    a.in2 = tv_ptr(e, op.in2, ins, n_in, outs, n_out);
+                    a.in2_cin = op.in2_cin; a.ldi2 = op.in2.ld; a.in2_up2 = op.in2_up2;
+                    const double e2 = ((double)op.in2.B * op.in2.H * op.in2.W - 1.0) * op.in2.ld * dtype_size(op.cdt) + (double)op.in2_cin * dtype_size(op.cdt);
+                    a.in2_bytes = e2 < 2147483000.0 ? (unsigned)e2 : 0u;
+                }
                 if (op.wid1 >= 0) {
                     const DevConv& d1 = e.convs[op.wid1];
                     a.c1_w = d1.w; a.c1_bias = d1.bias; a.c1_Kpad = d1.Kpad; a.c1_res = op.c1_res;
@@ -1485,6 +1522,12 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                         a.B = nb;
                         a.M = nb * a.Ho * a.Wo;
                         a.in = (const char*)a0.in + (size_t)(in_img * b0);
+                        if (a0.in2) {       // the second input of a 1x1 convolution: its own image size
+                            const double img2 = (double)op.in2.H * op.in2.W * a.ldi2 * dtype_size(op.cdt);
+                            a.in2 = (const char*)a0.in2 + (size_t)(img2 * b0);
+                            const double e2 = ((double)nb * op.in2.H * op.in2.W - 1.0) * a.ldi2 * dtype_size(op.cdt) + (double)op.in2_cin * dtype_size(op.cdt);
+                            a.in2_bytes = e2 < 2147483000.0 ? (unsigned)e2 : 0u;
+                        }
                         const double iext = raw_in ? in_img * nb : ((double)nb * a.H * a.W - 1.0) * a.ldi * dtype_size(op.cdt) + (double)op.cin * dtype_size(op.cdt);
                         a.in_bytes = iext < 2147483000.0 ? (unsigned)iext : 0u;
                         if (op.head) {
@@ -1648,6 +1691,7 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_HEAD_STREAM")) o |= OPT_NO_HEAD_STREAM;
     if (env("SKY_NO_BNECK128")) o |= OPT_NO_BNECK128;
     if (env("SKY_NO_DEEP3X3")) o |= OPT_NO_DEEP3X3;
+    if (env("SKY_NO_IN2")) o |= OPT_NO_IN2;
     if (const char* v = env("SKY_HEAD_STREAM")) o |= v[0] == 'f' ? OPT_HEAD_STREAM_FORCE : 0u;
     if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
     return o;
@@ -1763,7 +1807,7 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
     tw.cfg.dtype = SKY_BF16;
     tw.dtype = SKY_BF16;
     tw.weights = e.weights;
-    tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN | OPT_NO_CSP_STAGE;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
+    tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN | OPT_NO_CSP_STAGE | OPT_NO_IN2;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
     tw.mask_opts = OPT_FUSE;            // like the fp8 plan itself: an op computed in its producer's epilogue would never reach its amax reduction
     plan(tw, geometry_of(n_inputs, inputs));
     if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");
@@ -2043,7 +2087,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     const Op& op = h->e.ops[index];
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
-                 op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? " +res" : "", op.up2 ? " up2" : "",
+                 op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? (op.in2_cin ? " +res in2" : " +res") : (op.in2_cin ? " in2" : ""), op.up2 ? " up2" : "",
                  op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 7128 ? "bneck" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);

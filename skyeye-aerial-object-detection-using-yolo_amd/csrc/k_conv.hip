@@ -463,6 +463,10 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
     if (fused) *fused = 0;
+    if (a.in2) {                        // planned with a second input: only the streaming kernel reads one (engine checks conv_accepts_in2)
+        const hipError_t e2 = launch_conv_stream(dtype, a, s, variant, fused);
+        return e2 == hipErrorNotSupported ? hipErrorInvalidValue : e2;
+    }
     if (a.head && !(a.opts & OPT_NO_STREAM)) {
         const hipError_t e = launch_head_stream(dtype, a, s, variant);
         if (e != hipErrorNotSupported) return e;

@@ -128,14 +128,30 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     // load-side pixel state of the tile being fetched (decoded once per tile): 32-bit byte offset of the pixel's
     // top-left tap and a 9-bit "tap is inside the image" mask
     int lvo[MF], okm[MF];
+    // second input (ConvArgs::in2, 1x1 only): byte offset of this lane's pixel in it, and the slabs of K it provides
+    const bool dual = KS == 1 && a.in2 != nullptr;
+    const int nsplit = dual ? (a.in2_cin * (int)sizeof(T)) / SLAB : 0;
+    int lvo2[MF];
     auto decode_tile = [&](int tt) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int m = tt * TPX + i * 16 + lpix;
+            if (KS == 1) lvo2[i] = 0;
             if (m >= a.M || tt >= t_end) { lvo[i] = 0; okm[i] = 0; continue; }
             if (KS == 1) {
                 lvo[i] = m * a.ldi * (int)sizeof(T);
                 okm[i] = 1;
+                if (dual) {
+                    int m2 = m;
+                    if (a.in2_up2) {
+                        const int x = m % a.Wo;
+                        const int q = m / a.Wo;
+                        const int y = q % a.Ho;
+                        const int b = q / a.Ho;
+                        m2 = (b * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1);
+                    }
+                    lvo2[i] = m2 * a.ldi2 * (int)sizeof(T);
+                }
             } else {
                 const int ox = m % a.Wo;
                 const int q = m / a.Wo;
@@ -154,7 +170,29 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
         }
     };
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dual ? a.in2 : a.in), 0, (int)(dual ? a.in2_bytes : a.in_bytes), 0x00020000);
     auto load_slab = [&](u32x4_t (&dst)[MF][4], int ss) {
+        if (KS == 1 && dual) {
+            // whole slabs belong to one input: the first nsplit to in2 (read at the up2-mapped pixel), the rest to `in`
+            const bool from2 = ss < nsplit;
+            const int sb = from2 ? ss : ss - nsplit;
+            const int cpt1 = from2 ? (a.in2_cin * (int)sizeof(T)) >> 4 : cpt - ((a.in2_cin * (int)sizeof(T)) >> 4);
+#pragma unroll
+            for (int kk = 0; kk < (ONE ? KT : 4); ++kk) {
+                const int c0 = (sb * 4 + kk) * 4;
+                const int c = UTAP ? c0 : c0 + lch;
+                const bool kok = c < cpt1;
+                const int koff = c * 16 + (UTAP ? lch * 16 : 0);
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const bool ok = kok && okm[i];
+                    dst[i][kk] = from2 ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, ok ? lvo2[i] + koff : -1, 0, 0)
+                                       : __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? lvo[i] + koff : -1, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < (ONE ? KT : 4); ++kk) {
             const int c0 = (ss * 4 + kk) * 4;                 // first 16-byte chunk of this K-step (wave-uniform)
@@ -562,10 +600,29 @@ static hipError_t stream_dispatch_t(const StreamPlan& p, const ConvArgs& a, hipS
 }
 
 // returns hipErrorNotSupported when the shape is not covered (caller falls back to the implicit-GEMM kernel)
+// second input (ConvArgs::in2): whole 256-byte slabs of K from it, 1x1, the up2 mapping needs even output sides
+static bool in2_ok(int dtype, const ConvArgs& a)
+{
+    const int esz = dtype_size(dtype);
+    if (a.ks != 1 || a.stride != 1 || a.head || a.src_mode || a.f2_w || a.up2) return false;
+    if (a.in2_cin <= 0 || a.in2_cin >= a.Cin || ((long)a.in2_cin * esz) % SLAB != 0 || ((long)(a.Cin - a.in2_cin) * esz) % 16 != 0) return false;
+    if (a.in2_bytes == 0 || a.in_bytes == 0 || a.ldi2 % (16 / esz) != 0) return false;
+    if (a.in2_up2 && ((a.Ho | a.Wo) & 1)) return false;
+    return !(a.opts & (OPT_NO_STREAM | OPT_NO_IN2));
+}
+
+bool conv_accepts_in2(int dtype, const ConvArgs& a)
+{
+    if (!in2_ok(dtype, a)) return false;
+    if (a.out_dt >= 0 && a.out_dt != dtype && !(dtype == 2 && a.out_dt == 1)) return false;
+    return stream_plan(dtype, a).nf != 0;
+}
+
 hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     if (a.src_mode) return hipErrorNotSupported;
+    if (a.in2 && !in2_ok(dtype, a)) return hipErrorNotSupported;
     const bool mixed = a.out_dt >= 0 && a.out_dt != dtype;
     // mixed types: fp8 operands with a bf16 output (the fp8 engine's last neck convolutions, 1x1, no residual) run here; the rest
     // (its bf16 stem on shapes the narrow halo kernel leaves) on the tile kernel

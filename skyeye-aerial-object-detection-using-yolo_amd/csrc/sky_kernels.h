@@ -37,6 +37,7 @@ enum PlanOpt : unsigned {
     OPT_HEAD_STREAM_FORCE = 1u << 22,// SKY_HEAD_STREAM=force the streaming head kernel on small levels too (default: only where 32-pixel steps fill the device)
     OPT_NO_BNECK128 = 1u << 23,      // SKY_NO_BNECK128      128-channel bottlenecks as two launches (default: one kernel, k_bneck.hip)
     OPT_NO_DEEP3X3 = 1u << 24,       // SKY_NO_DEEP3X3       wide 3x3 stride-1 layers on the halo-tile kernel (default: k_conv3x3_deep.hip where covered)
+    OPT_NO_IN2 = 1u << 25,           // SKY_NO_IN2           neck concat buffers materialised (default: the upsampled half is read from the small map)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -98,6 +99,12 @@ struct ConvArgs {
     int c1_Kpad, c1_res;
     unsigned out_bytes, res_bytes;   // extents of the output / residual views in bytes (0 = 2 GiB or more)
     unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)
+    // optional second input of a 1x1 convolution (streaming kernel): the first in2_cin channels of K come from `in2`, read with the
+    // nearest-2x upsampling of FeatureNeck (detector.py:214,218: output pixel (y, x) <- in2 pixel (y >> 1, x >> 1)) when in2_up2, the
+    // remaining Cin - in2_cin channels from `in` -- cat([up(lateral(p)), q]) is then never materialised for its first half
+    const void* in2;
+    int in2_cin, ldi2, in2_up2;
+    unsigned in2_bytes;
     // detection-level epilogue (DetectionHead.forward + process_detections, detector.py:61-145)
     int head;
     float* raw;          // [B, na, gh, gw, no] fp32
@@ -136,6 +143,8 @@ hipError_t launch_conv_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* variant = nullptr, int* fused = nullptr);
 // would launch_conv run this (3x3, stride 1, 16-channel) convolution on the kernel that reads raw frames (ConvArgs::src_mode)?
 bool conv_accepts_raw(int dtype, const ConvArgs& a);
+// would launch_conv run this 1x1 convolution with a second input (ConvArgs::in2*)?  (plan-time query)
+bool conv_accepts_in2(int dtype, const ConvArgs& a);
 // would launch_conv run this 3x3 convolution with the preceding 1x1 (ConvArgs::c1_*) fused on the halo tile?  (plan-time query:
 // the engine then emits one launch for the cv1 + cv2 pair of a BottleneckBlock and gives it an output that does not alias x)
 bool conv_accepts_cv1(int dtype, const ConvArgs& a);
