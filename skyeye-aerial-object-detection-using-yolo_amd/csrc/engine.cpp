@@ -83,6 +83,7 @@ struct Op {
     int csp_stage = 0;     // cv1|cv2 of a CSPBlock whose whole stage (this op and the next three) can run as ONE kernel (k_csp_stage.hip)
     int csp_member = 0;    // one of those next three ops: skipped at run time when the stage kernel ran
     int csp_shortcut = 0;
+    int head_op = -1;      // a 1x1 128 -> 128 convolution whose output a detection level reads: index of that level's op (cv3 + level in one kernel, k_head.hip)
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 0, up2 = 0;
     int head = 0, level = 0;
     int raw_ext = -1, det_ext = -1;
@@ -1042,6 +1043,19 @@ static void head(Ctx& c, const std::string& p, const TV* feats, int nl, int nc, 
         op.wid = c.pack_conv({{l + "weight", "", l + "bias"}}, f.C, f.C, 1, op.cdt);
         op.flops = 2.0 * f.B * f.H * f.W * (double)(na * no) * f.C;
         c.push(op);
+        if (c.emit && !(c.e.opts & OPT_NO_CV3_HEAD) && f.C == 128 && f.dt == SKY_BF16 && f.buf >= 0) {
+            // the convolution that writes this level's input (CSP cv3): both can run as one kernel (launch_cv3_head decides at run time)
+            const int hi = (int)c.e.ops.size() - 1;
+            for (int k = hi - 1; k >= 0; --k) {
+                Op& pr = c.e.ops[k];
+                if (pr.out.buf != f.buf) continue;
+                if (pr.kind == OP_CONV && !pr.head && pr.out.off == f.off && pr.out.ld == f.ld && pr.ks == 1 && pr.stride == 1 && pr.cin == 128 && pr.cout == 128 &&
+                    pr.act == ACT_SILU && !pr.up2 && !pr.res.valid() && !pr.in2.valid() && pr.wid1 < 0 && !pr.fuse_next && !pr.fused_prev && !pr.csp_member &&
+                    pr.cdt == SKY_BF16 && pr.out.dt == SKY_BF16)
+                    pr.head_op = hi;
+                break;                                         // (the last writer of the buffer, whatever it is)
+            }
+        }
         off += (long)na * f.H * f.W;
         if (c.emit) {
             IoInfo io;
@@ -1315,8 +1329,16 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
     StemDownArgs stem_down_args;
     memset(&stem_down_args, 0, sizeof(stem_down_args));
     int sl_b0 = 0, sl_nb = -1;       // batch slice the ops run on (sl_nb < 0: the whole batch)
+    unsigned head_done = 0;          // detection levels already computed by the kernel of the convolution that feeds them
     auto exec_op = [&](size_t oi) {
         Op& op = e.ops[oi];
+        if (op.kind == OP_CONV && op.head && (head_done >> op.level & 1u)) {
+            head_done &= ~(1u << op.level);
+            op.variant = 9000;
+            ++op_index;
+            if (marks) SKY_HIP(hipEventRecord(marks[op_index], s));
+            return;
+        }
         if (op.fused_prev && took_next) {
             took_next = false;
             op.variant = 9000;
@@ -1498,6 +1520,30 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 if (op.wid1 >= 0) {
                     const DevConv& d1 = e.convs[op.wid1];
                     a.c1_w = d1.w; a.c1_bias = d1.bias; a.c1_Kpad = d1.Kpad; a.c1_res = op.c1_res;
+                }
+                if (op.head_op >= 0 && !amax && sl_nb < 0 && !a.f2_w && !a.src_mode) {
+                    // CSP cv3 + the detection level that reads it: one kernel (k_head.hip), the level's op is skipped when it comes
+                    const Op& h = e.ops[op.head_op];
+                    const DevConv& dh = e.convs[h.wid];
+                    ConvArgs f = a;
+                    f.f2_w = dh.w; f.f2_bias = dh.bias; f.f2_Kpad = dh.Kpad;
+                    TV r; r.ext = h.raw_ext;
+                    TV dt; dt.ext = h.det_ext;
+                    f.raw = (float*)tv_ptr(e, r, ins, n_in, outs, n_out);
+                    f.det = (float*)tv_ptr(e, dt, ins, n_in, outs, n_out);
+                    f.na = cf.num_anchors; f.no = cf.nc + 5;
+                    f.det_rows = h.det_rows; f.det_off = h.det_off; f.stride_px = h.stride_px;
+                    for (int k = 0; k < cf.num_anchors * 2; ++k) f.anchor_wh[k] = cf.anchors[h.level * cf.num_anchors * 2 + k] * h.stride_px;
+                    const double fout = (double)a.M * a.ldo * 2;
+                    if (h.level < 32 && a.in_bytes != 0 && fout < 2147483000.0 && tv_scale(e, op.out) == 1.0f && cv3_head_supported(op.cdt, f)) {
+                        const hipError_t he = launch_cv3_head(op.cdt, f, s);
+                        if (he == hipSuccess) {
+                            op.variant = 1628;
+                            head_done |= 1u << h.level;
+                            break;
+                        }
+                        if (he != hipErrorNotSupported) SKY_HIP(he);
+                    }
                 }
                 int fused = 0;
                 // The kernels address a view with 32-bit byte offsets (buffer descriptors): a view of 2 GiB or more (skyeye_l's
@@ -1692,6 +1738,7 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_BNECK128")) o |= OPT_NO_BNECK128;
     if (env("SKY_NO_DEEP3X3")) o |= OPT_NO_DEEP3X3;
     if (env("SKY_NO_IN2")) o |= OPT_NO_IN2;
+    if (env("SKY_NO_CV3_HEAD")) o |= OPT_NO_CV3_HEAD;
     if (const char* v = env("SKY_HEAD_STREAM")) o |= v[0] == 'f' ? OPT_HEAD_STREAM_FORCE : 0u;
     if (const char* v = env("SKY_HALO_SKIP")) o |= ((unsigned)atoi(v) & 31u) << OPT_SKIP_SHIFT;
     return o;
@@ -2088,7 +2135,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? (op.in2_cin ? " +res in2" : " +res") : (op.in2_cin ? " in2" : ""), op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 7128 ? "bneck" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 7128 ? "bneck" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)

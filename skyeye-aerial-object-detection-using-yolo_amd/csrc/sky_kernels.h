@@ -38,6 +38,7 @@ enum PlanOpt : unsigned {
     OPT_NO_BNECK128 = 1u << 23,      // SKY_NO_BNECK128      128-channel bottlenecks as two launches (default: one kernel, k_bneck.hip)
     OPT_NO_DEEP3X3 = 1u << 24,       // SKY_NO_DEEP3X3       wide 3x3 stride-1 layers on the halo-tile kernel (default: k_conv3x3_deep.hip where covered)
     OPT_NO_IN2 = 1u << 25,           // SKY_NO_IN2           neck concat buffers materialised (default: the upsampled half is read from the small map)
+    OPT_NO_CV3_HEAD = 1u << 26,      // SKY_NO_CV3_HEAD      fpn_conv3.cv3 and detection level 0 as two launches (default: one kernel, k_head.hip)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -187,6 +188,10 @@ struct CspStageArgs {
     int device, n_cu;
 };
 // detection level (1x1 + bias + decode) as a byte streamer, bf16 (k_head.hip); hipErrorNotSupported: take the tile kernel
+// CSP cv3 (1x1 128 -> 128) + the detection level that reads its output in one kernel (k_head.hip): `a` = the cv3 convolution, the level
+// in f2_w / f2_bias / f2_Kpad + the head fields
+bool cv3_head_supported(int dtype, const ConvArgs& a);
+hipError_t launch_cv3_head(int dtype, const ConvArgs& a, hipStream_t s);
 bool head_stream_supported(int dtype, const ConvArgs& a);
 hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant);
 
