@@ -123,8 +123,10 @@ FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded
     ("stem_down", "stem_down_kernel: frames -> FocusBlock 3x3 -> 3x3 stride 2 in one kernel", lambda v: 8000 <= v < 8500),
     ("csp_stage", "csp_stage_kernel: CSPBlock(64, 64, 1) = cv1|cv2 -> 1x1 -> 3x3 + shortcut -> cv3 in one kernel", lambda v: 8500 <= v < 9000),
     ("stream_resident", "conv_stream_kernel: 1x1 (and narrow 3x3), weights resident in LDS", lambda v: 2000 <= v < 3000),
+    ("gemm1x1", "gemm1x1_kernel: large-K 1x1 as a 256 x 256-tile GEMM, both operands by LDS-DMA", lambda v: v == 3256),
     ("stream_ring", "conv_stream_kernel: large-K 1x1, weight ring", lambda v: 3000 <= v < 4000),
-    ("tile", "conv_igemm_kernel: detection levels (N = 45) + fallback shapes", lambda v: 1000 <= v < 2000),
+    ("cv3_head", "cv3_head_kernel: CSP cv3 (1x1 128->128) + detection level 0 (conv + decode) in one kernel", lambda v: v == 1628),
+    ("tile", "conv_igemm_kernel / head_stream_kernel: detection levels (N = 45) + fallback shapes", lambda v: 1000 <= v < 2000),
 ]
 
 

@@ -463,6 +463,10 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* variant, int* fused)
 {
     if (fused) *fused = 0;
+    if (a.ks == 1 && !a.head) {         // large-K 1x1 layers: the GEMM where it applies
+        const hipError_t eg = launch_gemm1x1(dtype, a, s, variant);
+        if (eg != hipErrorNotSupported) return eg;
+    }
     if (a.in2) {                        // planned with a second input: only the streaming kernel reads one (engine checks conv_accepts_in2)
         const hipError_t e2 = launch_conv_stream(dtype, a, s, variant, fused);
         return e2 == hipErrorNotSupported ? hipErrorInvalidValue : e2;

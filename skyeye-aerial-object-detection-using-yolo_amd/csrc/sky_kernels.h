@@ -39,6 +39,8 @@ enum PlanOpt : unsigned {
     OPT_NO_DEEP3X3 = 1u << 24,       // SKY_NO_DEEP3X3       wide 3x3 stride-1 layers on the halo-tile kernel (default: k_conv3x3_deep.hip where covered)
     OPT_NO_IN2 = 1u << 25,           // SKY_NO_IN2           neck concat buffers materialised (default: the upsampled half is read from the small map)
     OPT_NO_CV3_HEAD = 1u << 26,      // SKY_NO_CV3_HEAD      fpn_conv3.cv3 and detection level 0 as two launches (default: one kernel, k_head.hip)
+    OPT_NO_GEMM1X1 = 1u << 27,       // SKY_NO_GEMM1X1       large-K 1x1 convolutions on the streaming kernel (default: the LDS-DMA GEMM, k_gemm1x1.hip)
+    OPT_GEMM1X1_FORCE = 1u << 28,    // SKY_GEMM1X1=force    the GEMM wherever the shape is covered (default: K >= 256 and two tiles per CU or more)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -192,6 +194,9 @@ struct CspStageArgs {
 // in f2_w / f2_bias / f2_Kpad + the head fields
 bool cv3_head_supported(int dtype, const ConvArgs& a);
 hipError_t launch_cv3_head(int dtype, const ConvArgs& a, hipStream_t s);
+// 1x1 convolutions with K >= 256 and Cout % 256 == 0 as a 128 x 256-tile GEMM fed by LDS-DMA (k_gemm1x1.hip); reads ConvArgs::in2 too
+bool gemm1x1_ok(int dtype, const ConvArgs& a);
+hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t s, int* variant);
 bool head_stream_supported(int dtype, const ConvArgs& a);
 hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* variant);
 

@@ -1,0 +1,120 @@
+"""The large-K 1x1 GEMM (csrc/k_gemm1x1.hip: 256-pixel x 256-channel tiles, both operands by LDS-DMA through a two-stage ring of 128-byte
+rows) against the streaming kernel it replaces (SKY_NO_GEMM1X1=1): same MFMA instruction, operand roles and K order, so
+ConvolutionBlock(k = 1) (reference blocks.py:10-41), the neck with its in-place concat (ConvArgs::in2, detector.py:210-229) and whole
+detectors are bit-identical -- on ragged pixel counts (tiles past M, waves without pixels), one and several N tiles, K from 192 to 1024
+channels, SiLU and no activation, and at the benchmark's B = 32 shapes where the GEMM is the default path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from skyeye.core.models import ConvolutionBlock
+from skyeye.core.models.detector import FeatureNeck
+from helpers import build_detector, detector_params, load_seeded, variant_cfg
+from seeded import seeded_input, seeded_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(gemm, force):
+    os.environ.pop("SKY_NO_GEMM1X1", None)
+    os.environ.pop("SKY_GEMM1X1", None)
+    if not gemm:
+        os.environ["SKY_NO_GEMM1X1"] = "1"
+    elif force:
+        os.environ["SKY_GEMM1X1"] = "force"
+
+
+def _clear():
+    os.environ.pop("SKY_NO_GEMM1X1", None)
+    os.environ.pop("SKY_GEMM1X1", None)
+
+
+def _conv(cin, cout, act, x, gemm, force=True):
+    _env(gemm, force)
+    try:
+        m = load_seeded(ConvolutionBlock(cin, cout, 1, 1, activation=act), 17).eval().set_precision("bf16")
+        y = m(x)
+        h = m._engine([x])
+        info = [h.op_info(i) for i in range(h.stats()["launches"])]
+    finally:
+        _clear()
+    return y, info
+
+
+@pytest.mark.parametrize("cin,cout,shape,act", [
+    (512, 512, (2, 40, 40), True), (256, 256, (1, 13, 9), True), (1024, 512, (1, 20, 24), True), (192, 256, (3, 7, 5), True),
+    (768, 512, (2, 17, 23), False), (512, 256, (2, 80, 80), True), (384, 256, (1, 31, 33), True), (256, 1024, (1, 12, 20), True),
+    (192, 512, (1, 128, 1), True)], ids=lambda v: str(v).replace(" ", ""))
+def test_gemm1x1_equals_stream_kernel(cin, cout, shape, act):
+    B, H, W = shape
+    x = torch.from_numpy(seeded_input("g1.%d.%d.%d.%d" % (cin, B, H, W), (B, cin, H, W), 5, -2.0, 2.0)).cuda()
+    y_g, info_g = _conv(cin, cout, act, x, True)
+    y_s, info_s = _conv(cin, cout, act, x, False)
+    assert any("gemm1x1" in t for t in info_g), info_g
+    assert not any("gemm1x1" in t for t in info_s), info_s
+    assert bool(torch.isfinite(y_g).all())
+    assert torch.equal(y_g, y_s), f"{int((y_g != y_s).sum())} of {y_g.numel()} values differ"
+
+
+def test_gemm1x1_default_choice():
+    """Cin >= 512, Cout >= 512 and half a tile per CU or more: the GEMM without the force switch; small maps stay on the streaming kernel."""
+    x = torch.from_numpy(seeded_input("g1.big", (32, 512, 40, 40), 6, -2.0, 2.0)).cuda()
+    y_g, info = _conv(512, 512, True, x, True, force=False)
+    assert any("gemm1x1" in t for t in info), info
+    y_s, _ = _conv(512, 512, True, x, False)
+    assert torch.equal(y_g, y_s)
+    x = torch.from_numpy(seeded_input("g1.small", (1, 512, 20, 20), 6, -2.0, 2.0)).cuda()
+    _, info = _conv(512, 512, True, x, True, force=False)
+    assert not any("gemm1x1" in t for t in info), info
+
+
+@pytest.mark.parametrize("hw", [(40, 40), (24, 56), (20, 36)])
+def test_neck_second_input_through_the_gemm(hw):
+    B, (H5, W5) = 2, hw
+    feats = [torch.from_numpy(seeded_input("g1n.p%d.%d.%d" % (i, H5, W5), (B, c, H5 * s, W5 * s), 3 + i, -2.0, 2.0)).cuda()
+             for i, (c, s) in enumerate([(128, 4), (256, 2), (512, 1)])]
+
+    def neck(gemm):
+        _env(gemm, True)
+        try:
+            m = load_seeded(FeatureNeck([128, 256, 512], width_multiple=1.0), 31).set_precision("bf16")
+            outs = m(feats)
+            h = m._engine(list(feats))
+            return outs, [h.op_info(i) for i in range(h.stats()["launches"])]
+        finally:
+            _clear()
+
+    a, info_a = neck(True)
+    b, info_b = neck(False)
+    assert any(" in2" in t and "gemm1x1" in t for t in info_a), info_a
+    assert not any("gemm1x1" in t for t in info_b)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), f"{int((x != y).sum())} of {x.numel()} values differ"
+
+
+@pytest.mark.parametrize("variant,shape", [("skyeye_s", (2, 320, 320)), ("skyeye_s", (1, 1280, 1280)), ("skyeye_l", (2, 128, 96)), ("skyeye_s", (3, 96, 160))],
+                         ids=lambda v: v if isinstance(v, str) else "b%d_%dx%d" % v)
+def test_detector_with_and_without_the_gemm(variant, shape):
+    P = detector_params(variant)
+    B, H, W = shape
+    x = torch.from_numpy(seeded_scene(B, H, W, 43)).cuda()
+
+    def run(gemm):
+        _env(gemm, True)
+        try:
+            m = build_detector(variant_cfg(variant))
+            m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()}, strict=True)
+            m = m.eval().set_precision("bf16")
+            d, raw = m(x)
+            h = m._engine([m._prepare_input(x)])
+            return d, raw, [h.op_info(i) for i in range(h.stats()["launches"])]
+        finally:
+            _clear()
+
+    d0, r0, i0 = run(True)
+    d1, r1, i1 = run(False)
+    assert sum("gemm1x1" in t for t in i0) >= 8, i0
+    assert not any("gemm1x1" in t for t in i1)
+    assert torch.equal(d0, d1) and all(torch.equal(p, q) for p, q in zip(r0, r1))

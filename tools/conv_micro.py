@@ -13,13 +13,14 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 if len(sys.argv) > 2:
     cases = [cases[int(i)] for i in sys.argv[2].split(",")]
 iters = int(os.environ.get("MICRO_ITERS", "5"))
+B = int(os.environ.get("MICRO_B", "32"))
 for cin, cout, k, s, hw in cases:
     m = ConvolutionBlock(cin, cout, k, s, activation=os.environ.get("MICRO_NOACT") is None).eval().set_precision(prec)
-    x = torch.randn(32, cin, hw, hw, device="cuda")
+    x = torch.randn(B, cin, hw, hw, device="cuda")
     m(x)
     h = m._engine([x])
     outs = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in h.output_shapes()]
     prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], torch.cuda.current_stream().cuda_stream, iters=iters)
     ms, fl, _ = prof[1]
-    byts = 32 * hw * hw * (cin + cout) * (2 if prec == "bf16" else 4)
-    print(f"dbg={os.environ.get('SKY_CONV_DBG','0'):>2} {prec} conv{k}x{k} {cin}->{cout} @{hw}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s  {byts/ms/1e9:7.2f} TB/s(in+out)")
+    byts = B * hw * hw * (cin + cout) * (2 if prec == "bf16" else 4)
+    print(f"B={B} dbg={os.environ.get('SKY_CONV_DBG','0'):>2} {prec} conv{k}x{k} {cin}->{cout} @{hw}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s  {byts/ms/1e9:7.2f} TB/s(in+out)")

@@ -57,3 +57,23 @@ for f in range(4):
             A = f * HPL + p * 32
             ok &= dst == A + ((((A >> 8) & 1) ^ kk) << 4)
 print("halo DMA layout consistent with reads:", ok)
+
+
+# k_gemm1x1.hip: rows of ROWB bytes, chunk c of row r (index within its 16-row fragment) in slot c ^ swz(r); lane (fr, fq) reads row fr, chunk ks * 4 + fq
+def g1_addr(lane, rowb, ks):
+    fr, fq = lane & 15, lane >> 4
+    sw = ((fr >> 3) & 1) * 3 if rowb == 64 else (fr >> 1) & 7
+    return (fr * rowb + ((fq ^ sw) << 4)) ^ (ks << 6)
+
+
+for rowb, kss in ((64, 1), (128, 2)):
+    print("gemm1x1 fragment reads, %d-byte rows: worst cycles per ds_read_b128 =" % rowb, max(cycles(lambda l: g1_addr(l, rowb, ks)) for ks in range(kss)))
+    ch = rowb // 16
+    ok = True
+    for piece in range(16 // (1024 // rowb)):
+        for l in range(64):
+            row = piece * (1024 // rowb) + l // ch
+            sw = ((row >> 3) & 1) * 3 if rowb == 64 else (row >> 1) & 7
+            chunk = (l % ch) ^ sw                      # what the DMA lane fetches; it lands at piece * 1024 + l * 16
+            ok &= piece * 1024 + l * 16 == row * rowb + ((chunk ^ sw) << 4)
+    print("gemm1x1 DMA layout consistent with reads:", ok)

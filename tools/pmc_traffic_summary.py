@@ -36,6 +36,10 @@ for k, v in agg.items():
         variant = 7128
     elif "conv3x3_deep_kernel" in k:
         variant = 4728
+    elif "cv3_head_kernel" in k:
+        variant = 1628
+    elif "gemm1x1_kernel" in k:
+        variant = 3256
     elif "head_stream_kernel" in k:
         variant = 1548
     elif "conv_halo_kernel" in k:
