@@ -23,6 +23,10 @@ def family(k):
         return "bneck128"
     if "conv3x3_deep_kernel" in k:
         return "deep3x3"
+    if "gemm1x1_kernel" in k:
+        return "gemm1x1"
+    if "cv3_head_kernel" in k:
+        return "cv3_head"
     if "head_stream_kernel" in k:
         return "tile"                # detection levels: same family as the tile kernel's head launches
     if "conv_halo_kernel" in k and (re.search(r"Lb1EEEvNS_8ConvArgsE$", k.split("(")[0]) or re.search(r", true>$", k.split("(")[0])):
