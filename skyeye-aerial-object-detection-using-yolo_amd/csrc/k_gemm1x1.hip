@@ -37,7 +37,7 @@ namespace sky {
 #endif
 
 namespace g1 {
-constexpr int MAXC = 1024;                                     // bias of every output channel stays in LDS
+constexpr int MAXC = 2048;                                     // bias of every output channel stays in LDS
 // NWM x NWN waves, a wave owns 64 pixels x NFJ * 16 channels; ROWB bytes of K per row and step; NST ring stages
 template <int NWM_, int NWN_, int NFJ_, int ROWB_, int NST_>
 struct Geo {
@@ -92,7 +92,9 @@ __device__ __forceinline__ void g1_wait(int younger, bool st)
     }
 }
 
-template <typename GEO>
+// RES: a residual (ConvArgs::res, the output's element type) is added behind the activation (TransformerLayer's x + proj(..) / x + ffn(..),
+// reference attention.py:244-309); its 16-byte vectors are loaded one pixel fragment ahead, the first four under the tile's last MFMAs
+template <typename GEO, bool RES>
 __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 {
     using namespace g1;
@@ -127,6 +129,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dual ? a.in2 : a.in), 0, (int)(dual ? a.in2_bytes : a.in_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)((long)a.Cout * wpitch), 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(RES ? a.res : a.in), 0, (int)(RES ? a.res_bytes : a.in_bytes), 0x00020000);
 
     // ---- DMA side: lane l of a piece writes row (l / CH), slot (l % CH) of its RPP rows and fetches chunk slot ^ swz(row) ----
     const int drow = lane / CH, dslot = lane % CH;
@@ -215,6 +218,14 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
         g1_barrier();
         if (g + LEAD < total && !G1_OFF(2)) issue(stage == 0 ? NST - 1 : stage - 1);   // stage (g + LEAD) % NST: read last in step g - 1, before this barrier
         const char* const sb = smem + stage * STG;
+        Out8<__bf16>::raw_t rres[2][NFJ / 2];
+        if (RES && c_k == nk - 1) {                            // residual vectors of pixel fragment 0: under this step's MFMAs
+            const int mt = c_item / gy, nt = c_item - mt * gy;
+            const int m = mt * TM + wm * 64 + fr;
+            const int rb = m < a.M ? (m * a.ldr + nt * TN + wn * (NFJ * 16) + fq * 8) * 2 : -1;
+#pragma unroll
+            for (int sg = 0; sg < NFJ / 2; ++sg) rres[0][sg] = Out8<__bf16>::load(rrsrc, rb < 0 ? -1 : rb + sg * 64, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < KSS; ++ks) {
             // all fragment reads of a K-step go out before its first MFMA (counted lgkmcnt waits follow from the order): hipcc otherwise
@@ -245,6 +256,11 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
             for (int i = 0; i < 4; ++i) {
                 const int m = mt * TM + wm * 64 + i * 16 + fr;
                 const int obase = m < a.M ? (m * a.ldo + n0 + fq * 8) * 2 : -1;
+                if (RES && i < 3) {
+                    const int rb = m + 16 < a.M ? ((m + 16) * a.ldr + n0 + fq * 8) * 2 : -1;
+#pragma unroll
+                    for (int sg = 0; sg < NFJ / 2; ++sg) rres[(i + 1) & 1][sg] = Out8<__bf16>::load(rrsrc, rb < 0 ? -1 : rb + sg * 64, 0);
+                }
 #pragma unroll
                 for (int sg = 0; sg < NFJ / 2; ++sg) {
                     const int nl = n0 + sg * 32 + fq * 8;
@@ -263,6 +279,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     }
+                    if (RES) Out8<__bf16>::add(rres[i & 1][sg], v, a.res_scale);
                     const Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
                     Out8<__bf16>::store(o, orsrc, obase < 0 ? -1 : obase + sg * 64);      // (always issued: the waits count it)
 #pragma unroll
@@ -297,13 +314,14 @@ bool gemm1x1_ok(int dtype, const ConvArgs& a)
 {
     using namespace g1;
     if (dtype != 1 || (a.out_dt >= 0 && a.out_dt != 1)) return false;
-    if (a.ks != 1 || a.stride != 1 || a.head || a.up2 || a.res || a.src_mode || a.f2_w || a.c1_w || a.out_f32) return false;
+    if (a.ks != 1 || a.stride != 1 || a.head || a.up2 || a.src_mode || a.f2_w || a.c1_w || a.out_f32) return false;
     const int shape = g1_shape(a);
     const int tn = shape == 1 ? 128 : 256, kstep = shape == 0 ? 32 : 64;
     if (a.Cout % tn != 0 || a.Cout > MAXC || a.Cin % kstep != 0 || a.Cin < 3 * kstep || a.Kpad < a.Cin) return false;
     if (a.ldi % 8 != 0 || a.ldo % 8 != 0 || a.in_bytes == 0 || a.out_bytes == 0 || a.M <= 0) return false;
     if ((reinterpret_cast<size_t>(a.in) | reinterpret_cast<size_t>(a.out) | reinterpret_cast<size_t>(a.w)) & 15) return false;
     if ((double)a.Cout * a.Kpad * 2 >= 2147483000.0) return false;
+    if (a.res && (a.res_bytes == 0 || a.ldr % 8 != 0 || (reinterpret_cast<size_t>(a.res) & 15))) return false;
     if (a.in2) {
         if (a.in2_cin <= 0 || a.in2_cin >= a.Cin || a.in2_cin % kstep != 0 || a.in2_bytes == 0 || a.ldi2 % 8 != 0) return false;
         if (a.in2_up2 && ((a.Ho | a.Wo) & 1)) return false;
@@ -315,10 +333,10 @@ bool gemm1x1_ok(int dtype, const ConvArgs& a)
     // stage), from half a tile per CU up; at Cout = 256 the resident-weight streamer reads the pixels once and is as fast or faster
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const long items = (long)((a.M + 255) / 256) * (a.Cout / 256);
-    return shape == 2 && a.Cin >= 512 && a.Cout >= 512 && 2 * items >= n_cu;
+    return shape == 2 && (a.Cin >= 512 || a.Cout >= 768) && a.Cin >= 256 && a.Cout >= 512 && 2 * items >= n_cu;
 }
 
-template <typename GEO>
+template <typename GEO, bool RES = false>
 static hipError_t g1_launch(const ConvArgs& a, hipStream_t s, int per_cu)
 {
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
@@ -328,10 +346,10 @@ static hipError_t g1_launch(const ConvArgs& a, hipStream_t s, int per_cu)
     if (gx >= 8) gx &= ~7;                                     // whole XCD rounds (the item order in the kernel)
     static size_t attr[16] = {0};
     {
-        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(gemm1x1_kernel<GEO>), GEO::LDS_BYTES, a.device, attr);
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(gemm1x1_kernel<GEO, RES>), GEO::LDS_BYTES, a.device, attr);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(gemm1x1_kernel<GEO>, dim3(gx), dim3(GEO::NT), GEO::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm1x1_kernel<GEO, RES>), dim3(gx), dim3(GEO::NT), GEO::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
@@ -341,11 +359,11 @@ hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t s, int* vari
     const int shape = g1_shape(a);
     if (variant) *variant = 3256;
 #ifdef SKY_EXPERIMENTS
-    if (shape == 0) return g1_launch<GeoA>(a, s, 2);
-    if (shape == 1) return g1_launch<GeoB>(a, s, 2);
+    if (shape == 0 && !a.res) return g1_launch<GeoA>(a, s, 2);
+    if (shape == 1 && !a.res) return g1_launch<GeoB>(a, s, 2);
 #endif
     (void)shape;
-    return g1_launch<GeoC>(a, s, 1);
+    return a.res ? g1_launch<GeoC, true>(a, s, 1) : g1_launch<GeoC, false>(a, s, 1);
 }
 
 }  // namespace sky

@@ -1,7 +1,7 @@
 """The large-K 1x1 GEMM (csrc/k_gemm1x1.hip: 256-pixel x 256-channel tiles, both operands by LDS-DMA through a two-stage ring of 128-byte
 rows) against the streaming kernel it replaces (SKY_NO_GEMM1X1=1): same MFMA instruction, operand roles and K order, so
 ConvolutionBlock(k = 1) (reference blocks.py:10-41), the neck with its in-place concat (ConvArgs::in2, detector.py:210-229) and whole
-detectors are bit-identical -- on ragged pixel counts (tiles past M, waves without pixels), one and several N tiles, K from 192 to 1024
+detectors (also the head-attention variant: 1x1 with a residual, 1536 / 2048 output rows) are bit-identical -- on ragged pixel counts (tiles past M, waves without pixels), one and several N tiles, K from 192 to 1024
 channels, SiLU and no activation, and at the benchmark's B = 32 shapes where the GEMM is the default path."""
 import os
 
@@ -94,7 +94,8 @@ def test_neck_second_input_through_the_gemm(hw):
         assert torch.equal(x, y), f"{int((x != y).sum())} of {x.numel()} values differ"
 
 
-@pytest.mark.parametrize("variant,shape", [("skyeye_s", (2, 320, 320)), ("skyeye_s", (1, 1280, 1280)), ("skyeye_l", (2, 128, 96)), ("skyeye_s", (3, 96, 160))],
+@pytest.mark.parametrize("variant,shape", [("skyeye_s", (2, 320, 320)), ("skyeye_s", (1, 1280, 1280)), ("skyeye_l", (2, 128, 96)), ("skyeye_s", (3, 96, 160)),
+                                           ("skyeye_s_ha", (3, 256, 384)), ("skyeye_s_ha", (1, 1280, 1280))],
                          ids=lambda v: v if isinstance(v, str) else "b%d_%dx%d" % v)
 def test_detector_with_and_without_the_gemm(variant, shape):
     P = detector_params(variant)
@@ -116,5 +117,8 @@ def test_detector_with_and_without_the_gemm(variant, shape):
     d0, r0, i0 = run(True)
     d1, r1, i1 = run(False)
     assert sum("gemm1x1" in t for t in i0) >= 8, i0
+    if variant == "skyeye_s_ha":        # TransformerLayer: out_proj / FFN-down with the residual in the epilogue, QKV / FFN-up with up to 2048 rows
+        assert sum("gemm1x1" in t and "+res" in t for t in i0) >= 2, i0
+        assert any("->2048" in t and "gemm1x1" in t for t in i0), i0
     assert not any("gemm1x1" in t for t in i1)
     assert torch.equal(d0, d1) and all(torch.equal(p, q) for p, q in zip(r0, r1))
