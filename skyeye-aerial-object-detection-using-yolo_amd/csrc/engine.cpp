@@ -1050,7 +1050,7 @@ static void head(Ctx& c, const std::string& p, const TV* feats, int nl, int nc, 
                 Op& pr = c.e.ops[k];
                 if (pr.out.buf != f.buf) continue;
                 if (pr.kind == OP_CONV && !pr.head && pr.out.off == f.off && pr.out.ld == f.ld && pr.ks == 1 && pr.stride == 1 && pr.cin == 128 && pr.cout == 128 &&
-                    pr.act == ACT_SILU && !pr.up2 && !pr.res.valid() && !pr.in2.valid() && pr.wid1 < 0 && !pr.fuse_next && !pr.fused_prev && !pr.csp_member &&
+                    (pr.act == ACT_SILU || pr.act == ACT_NONE) && !pr.up2 && !pr.res.valid() && !pr.in2.valid() && pr.wid1 < 0 && !pr.fuse_next && !pr.fused_prev && !pr.csp_member &&
                     pr.cdt == SKY_BF16 && pr.out.dt == SKY_BF16)
                     pr.head_op = hi;
                 break;                                         // (the last writer of the buffer, whatever it is)

@@ -312,8 +312,12 @@ __global__ void __launch_bounds__(hd::NT) cv3_head_kernel(const ConvArgs a)
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = S1<__bf16>::silu(acc1[2 * sg][i][e] + b0[e]);
-                    v[4 + e] = S1<__bf16>::silu(acc1[2 * sg + 1][i][e] + b1[e]);
+                    v[e] = acc1[2 * sg][i][e] + b0[e];
+                    v[4 + e] = acc1[2 * sg + 1][i][e] + b1[e];
+                }
+                if (a.act == ACT_SILU) {                       // (ACT_NONE: the head-attention variant's output projection, attention.py:312-399)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = S1<__bf16>::silu(v[e]);
                 }
                 const Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
                 if (m < a.M) Out8<__bf16>::store(o, reinterpret_cast<char*>(a.out) + ((long)m * a.ldo + nl) * 2);
@@ -425,7 +429,7 @@ static size_t cv3_head_lds_bytes()
 // det_rows, det_off, stride_px, anchor_wh); M pixels
 bool cv3_head_supported(int dtype, const ConvArgs& a)
 {
-    return dtype == 1 && (a.out_dt < 0 || a.out_dt == 1) && a.ks == 1 && a.stride == 1 && a.Cin == hd2::C && a.Cout == hd2::C && a.act == ACT_SILU && !a.res &&
+    return dtype == 1 && (a.out_dt < 0 || a.out_dt == 1) && a.ks == 1 && a.stride == 1 && a.Cin == hd2::C && a.Cout == hd2::C && (a.act == ACT_SILU || a.act == ACT_NONE) && !a.res &&
            !a.up2 && !a.src_mode && !a.in2 && !a.c1_w && a.f2_w && a.f2_bias && a.f2_Kpad >= hd2::C && a.Kpad >= hd2::C && a.na >= 1 && a.no >= 1 &&
            a.na * a.no <= hd::NR && a.na <= 8 && a.ldi % 8 == 0 && a.ldo % 8 == 0 && a.in_bytes != 0 && a.det != nullptr && a.M > 0 &&
            a.no < 65536 / 16 && !(a.opts & (OPT_NO_STREAM | OPT_NO_HEAD_STREAM | OPT_NO_CV3_HEAD));

@@ -112,3 +112,16 @@ def test_cv3_head_not_taken_where_it_does_not_apply():
     x = torch.from_numpy(seeded_scene(2, 64, 64, 57)).cuda()
     _, _, info = _run(m, x, True, force=False, cv3_head=True)
     assert not any("cv3+head" in t for t in info)
+
+
+def test_cv3_head_pairs_the_output_projection_of_the_head_attention_variant():
+    """skyeye_s_ha: level 0 reads the window attention's output projection (1x1 128 -> 128, no activation): the same pairing, bit-identical."""
+    m = _detector("skyeye_s_ha")
+    x = torch.from_numpy(seeded_scene(3, 256, 384, 80)).cuda()
+    det_f, raw_f, info_f = _run(m, x, True, cv3_head=True)
+    det_s, raw_s, info_s = _run(m, x, True)
+    assert sum("cv3+head" in t for t in info_f) == 1, [t for t in info_f if "head" in t or "128->128" in t]
+    assert not any("cv3+head" in t for t in info_s)
+    assert torch.equal(det_f, det_s)
+    for a, b in zip(raw_f, raw_s):
+        assert torch.equal(a, b)
