@@ -471,7 +471,9 @@ static StreamPlan stream_plan(int dtype, const ConvArgs& a)
         p.nf = nf;
         return p;
     }
-    if (ring_ok) {                                                         // weights stream through a two-stage ring
+    // K of one or two slabs (<= 256 bf16 channels): an N tile's weights are loaded once per workgroup either way, and the resident form has no
+    // barrier per slab -- 128->384 @160x160 244 -> 216 us, 256->512 @80x80 119 -> 96 us (tools/conv_micro.py); beyond that the ring
+    if (ring_ok && !(fallback && nslab <= 2)) {                            // weights stream through a two-stage ring
         p.nf = 8;
         p.ring = true;
     } else {

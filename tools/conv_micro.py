@@ -8,7 +8,7 @@ import torch
 from skyeye import _native as N
 from skyeye.core.models import ConvolutionBlock
 
-cases = [(128, 128, 1, 1, 160), (128, 128, 3, 1, 80), (64, 64, 1, 1, 320), (64, 64, 3, 1, 160), (256, 256, 3, 1, 40), (32, 32, 3, 1, 320), (16, 32, 3, 1, 640), (64, 128, 3, 2, 320), (128, 256, 3, 2, 160), (128, 128, 3, 2, 160), (256, 512, 3, 2, 80), (512, 512, 1, 1, 40), (1024, 512, 1, 1, 40), (512, 256, 1, 1, 80), (256, 256, 1, 1, 80), (768, 512, 1, 1, 40), (384, 256, 1, 1, 80), (256, 128, 1, 1, 160), (256, 256, 1, 1, 40), (128, 128, 1, 1, 80), (64, 64, 1, 1, 160)]
+cases = [(128, 128, 1, 1, 160), (128, 128, 3, 1, 80), (64, 64, 1, 1, 320), (64, 64, 3, 1, 160), (256, 256, 3, 1, 40), (32, 32, 3, 1, 320), (16, 32, 3, 1, 640), (64, 128, 3, 2, 320), (128, 256, 3, 2, 160), (128, 128, 3, 2, 160), (256, 512, 3, 2, 80), (512, 512, 1, 1, 40), (1024, 512, 1, 1, 40), (512, 256, 1, 1, 80), (256, 256, 1, 1, 80), (768, 512, 1, 1, 40), (384, 256, 1, 1, 80), (256, 128, 1, 1, 160), (256, 256, 1, 1, 40), (128, 128, 1, 1, 80), (64, 64, 1, 1, 160), (128, 384, 1, 1, 160), (256, 768, 1, 1, 80), (128, 512, 1, 1, 160), (256, 512, 1, 1, 80)]
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 if len(sys.argv) > 2:
     cases = [cases[int(i)] for i in sys.argv[2].split(",")]
