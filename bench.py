@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--with-raw", action="store_true", help="also write the three raw detection levels (the reference's second return value)")
     ap.add_argument("--streams", type=int, default=2, help="run the batch as this many equal slices on parallel branches of the captured graph (each "
                     "slice has its own plan); 1 = the whole batch through one plan")
+    ap.add_argument("--no-pipeline", action="store_true", help="NMS of a batch strictly behind its own forward pass (default: the NMS of batch k runs beside the "
+                    "forward pass of batch k + 1, SkyEyeDetector.detect_nms_pipelined; every batch's NMS is inside the timed region)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 (shard), 5 (shard) behind the headline measurement")
     return ap.parse_args()
 
@@ -205,7 +207,7 @@ def main():
         if not a.no_graph:
             graph, held = capture_graph(local_step, warmup=2)                       # static shapes: one hipGraph replay per step
 
-        def step():
+        def sync_step():                                                            # one batch, forward then its own NMS (the latency figure)
             if graph is not None:
                 graph.replay()
                 rows, counts = held
@@ -215,19 +217,53 @@ def main():
                 rows, counts = all_gather_detections(rows, counts)                  # RCCL over xGMI
             return rows, counts
 
+        pipelined = not a.no_pipeline and not a.with_raw
+        if pipelined:
+            # throughput form: step k = forward(batch k) beside NMS(batch k - 1) (two buffer sets, two graphs replayed alternately);
+            # finish() = the last batch's NMS, inside the timed region: K steps do K forward passes and K + 1 NMS calls
+            def pipe_step(p):
+                return model.detect_nms_pipelined(x, a.conf, a.iou, max_detections=300, parity=p)
+            graphs = None if a.no_graph else [capture_graph(lambda p=p: pipe_step(p), warmup=2) for p in (0, 1)]
+            state = {"k": 0}
+
+            def step():
+                p = state["k"] & 1
+                state["k"] += 1
+                if graphs is not None:
+                    graphs[p][0].replay()
+                    res = graphs[p][1]
+                else:
+                    res = pipe_step(p)
+                if world > 1 and res is not None:
+                    res = all_gather_detections(*res)
+                return res
+
+            def finish():
+                res = model.detect_nms_flush(parity=(state["k"] - 1) & 1)
+                if world > 1:
+                    res = all_gather_detections(*res)
+                return res
+        else:
+            step = sync_step
+
+            def finish():
+                return None
+
         for _ in range(warmup):
             step()
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            rows, counts = step()
+            res = step()
+        last = finish()
+        rows, counts = last if last is not None else res
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dict(model=model, P=P, x=x, frames_np=frames_np, step=step, graph=graph, dt=dt, counts=counts)
+        return dict(model=model, P=P, x=x, frames_np=frames_np, step=sync_step, graph=graph, dt=dt, counts=counts, pipelined=pipelined)
 
     def fence():
         if world > 1:
@@ -288,6 +324,7 @@ def main():
                    "global_batch": world * B, "frames_per_gpu": B, "image_size": S, "candidates_target": "1% > conf",
                    "mean_boxes_kept_per_image": round(kept_mean, 1), "parallelism": f"dp{world} (independent images)",
                    "hip_graph": graph is not None, "raw_levels_written": bool(a.with_raw),
+                   "nms_one_batch_behind_forward": bool(leg.get("pipelined")),
                    "batch_slices_on_parallel_streams": a.streams if a.precision != "fp8" else 1},
     }
 

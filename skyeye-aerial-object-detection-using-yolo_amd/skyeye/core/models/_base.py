@@ -217,7 +217,8 @@ class NativeModule(nn.Module):
         if ent is not None:
             ent[0].close()
         if self._out_cache is not None:
-            self._out_cache.pop(key, None)
+            for k in [k for k in self._out_cache if k == key or (isinstance(k, tuple) and len(k) == 3 and k[0] in ("slot", "sliced") and k[-1] == key)]:
+                self._out_cache.pop(k, None)
 
     def half(self):
         """Reference callers use model.half() for the reduced-precision path (validate.py:195-197, detect.py:107-108).
@@ -324,12 +325,14 @@ class NativeModule(nn.Module):
             return self._run_sliced(inputs, extra_cfg, skip, nsl)
         key, h = self._engine_entry(inputs, extra_cfg)
         cache = self._out_cache
-        outs = cache.get(key) if cache is not None else None
+        slot = self.__dict__.get("_out_slot", 0)             # second set of reusable outputs (detect_nms_pipelined: two batches in flight)
+        ckey = ("slot", slot, key) if slot else key
+        outs = cache.get(ckey) if cache is not None else None
         if outs is None or any((o is None) != (i in skip) for i, o in enumerate(outs)):
             outs = [None if i in skip else torch.empty(s, dtype=torch.float32, device=inputs[0].device)
                     for i, s in enumerate(h.output_shapes())]
             if cache is not None:
-                cache[key] = outs
+                cache[ckey] = outs
         stream = torch.cuda.current_stream(inputs[0].device).cuda_stream
         h.forward([N.buffer_from_tensor(t) for t in inputs],
                   [N.null_buffer() if t is None else N.buffer_from_tensor(t) for t in outs], stream)
@@ -356,7 +359,7 @@ class NativeModule(nn.Module):
         ents = [self._engine_entry(parts[i], extra_cfg, slot=i + 1) for i in range(nsl)]       # (plans are made on the caller's stream)
         shapes = [(B,) + tuple(sh[1:]) for sh in ents[0][1].output_shapes()]
         cache = self._out_cache
-        ckey = ("sliced", ents[0][0])
+        ckey = ("sliced", self.__dict__.get("_out_slot", 0), ents[0][0])
         outs = cache.get(ckey) if cache is not None else None
         if outs is None or any((o is None) != (i in skip) for i, o in enumerate(outs)):
             outs = [None if i in skip else torch.empty(sh, dtype=torch.float32, device=dev) for i, sh in enumerate(shapes)]

@@ -208,6 +208,72 @@ class SkyEyeDetector(NativeModule):
         det = self._run([xi], skip=(1, 2, 3))[0]
         return nms_raw(det, conf_threshold, iou_threshold, max_detections=max_detections, **nms_kw)
 
+    def detect_nms_pipelined(self, x, conf_threshold=0.25, iou_threshold=0.45, max_detections=300, parity=None, **nms_kw):
+        """A two-deep software pipeline over a stream of batches (an extension; validate.py:245-255 / detect.py:140-145 run the pair
+        strictly one after the other): the forward pass of THIS batch is enqueued beside the non_max_suppression of the PREVIOUS one,
+        which otherwise runs alone behind the join -- a chain of seven small kernels on a few CUs, 0.145 of 4.35 ms on the benchmark
+        batch.  Returns (rows [B, max_det, 7], counts [B]) of the previous batch, or None for the first call; ``detect_nms_flush()``
+        returns the last batch's.  Two sets of detection / NMS buffers alternate (``parity`` 0 / 1; given explicitly when the two
+        forms are captured as two hipGraphs, else it toggles per call).  Needs ``reuse_output_buffers(True)``.  Same results as
+        ``detect_nms`` on every batch (tests/test_gpu_slices.py)."""
+        from ...utils.metrics import nms_raw
+        if self.training:
+            raise RuntimeError("detect_nms_pipelined is an eval-mode call")
+        if self._out_cache is None:
+            raise RuntimeError("detect_nms_pipelined needs reuse_output_buffers(True): two batches are in flight")
+        st = self.__dict__.setdefault("_pipe", {"parity": 0, "pending": None, "streams": {}})
+        p = st["parity"] if parity is None else int(parity) & 1
+        xi = self._prepare_input(x)
+        dev = xi.device
+        B = xi.shape[0]
+        cur = torch.cuda.current_stream(dev)
+        side = st["streams"].get(dev.index or 0)
+        if side is None:
+            side = st["streams"][dev.index or 0] = torch.cuda.Stream(device=dev)
+        if parity is not None and st.get(("det", 1 - p)) is None:            # explicit parity (graph capture): the other set must exist
+            self.__dict__["_out_slot"] = 2 - p
+            try:
+                st[("det", 1 - p)] = self._run([xi], skip=(1, 2, 3))[0]
+            finally:
+                self.__dict__["_out_slot"] = 0
+        prev = st["pending"] if parity is None else st.get(("det", 1 - p))
+        result = None
+        if prev is not None and prev.shape[0] == B:
+            ck = ("nms_pipe", B, int(max_detections), 1 - p)
+            bufs = self._out_cache.get(ck)
+            if bufs is None:
+                bufs = self._out_cache[ck] = (torch.empty((B, int(max_detections), 7), dtype=torch.float32, device=dev),
+                                              torch.empty((B,), dtype=torch.int32, device=dev))
+            side.wait_stream(cur)                                              # fork: the previous batch's detections are complete on `cur`
+            with torch.cuda.stream(side):
+                nms_raw(prev, conf_threshold, iou_threshold, max_detections=max_detections, out=bufs[0], counts=bufs[1], **nms_kw)
+            result = bufs
+        self.__dict__["_out_slot"] = 1 + p
+        try:
+            det = self._run([xi], skip=(1, 2, 3))[0]
+        finally:
+            self.__dict__["_out_slot"] = 0
+        if result is not None:
+            cur.wait_stream(side)                                              # join
+        st[("det", p)] = det
+        st["pending"] = det
+        st["last"] = (p, conf_threshold, iou_threshold, int(max_detections), dict(nms_kw))
+        if parity is None:
+            st["parity"] = 1 - p
+        return result
+
+    def detect_nms_flush(self, parity=None):
+        """non_max_suppression of the batch the last ``detect_nms_pipelined`` call ran forward: (rows, counts).  ``parity``: the set the
+        last REPLAYED graph wrote, when the calls were captured."""
+        from ...utils.metrics import nms_raw
+        st = self.__dict__.get("_pipe")
+        if not st or st.get("last") is None:
+            raise RuntimeError("detect_nms_flush: nothing in flight")
+        p, conf, iou, md, kw = st["last"]
+        if parity is not None:
+            p = int(parity) & 1
+        return nms_raw(st[("det", p)], conf, iou, max_detections=md, **kw)
+
     def warmup(self, imgsz=(1, 3, 640, 640)):
         """detect.py:126 calls model.warmup(imgsz=...)."""
         dev = next(self.parameters()).device

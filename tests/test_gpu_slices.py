@@ -67,3 +67,46 @@ def test_detect_nms_equals_forward_then_nms():
     torch.cuda.synchronize()
     assert torch.equal(counts, c0) and torch.equal(rows, r0)
     assert int(c0.max()) > 0
+
+
+def test_detect_nms_pipelined_equals_detect_nms_per_batch():
+    """NMS of batch k beside the forward pass of batch k + 1 (two buffer sets): every batch's rows / counts equal the unpipelined pair's, eagerly
+    (parity toggling) and as two captured hipGraphs replayed alternately (the bench's form)."""
+    from skyeye.utils.torch_utils import capture_graph
+    P = detector_params("skyeye_s")
+    m = build_detector(variant_cfg("skyeye_s"))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()}, strict=True)
+    m = m.eval().set_precision("bf16")
+    m.reuse_output_buffers(True)
+    m.parallel_slices(2)
+    xs = [torch.from_numpy(seeded_scene(4, 320, 320, 90 + i)).cuda() for i in range(4)]
+    want = []
+    for x in xs:
+        r, c = m.detect_nms(x, 0.05, 0.45, max_detections=100)
+        want.append((r.clone(), c.clone()))
+    got = []
+    for x in xs:
+        res = m.detect_nms_pipelined(x, 0.05, 0.45, max_detections=100)
+        if res is not None:
+            got.append((res[0].clone(), res[1].clone()))
+    r, c = m.detect_nms_flush()
+    got.append((r.clone(), c.clone()))
+    assert len(got) == len(want)
+    for (r0, c0), (r1, c1) in zip(want, got):
+        assert int(c0.sum()) > 0 and torch.equal(c0, c1) and torch.equal(r0, r1)
+    # two graphs, replayed alternately on a static input buffer
+    xin = xs[0].clone()
+    graphs = [capture_graph(lambda p=p: m.detect_nms_pipelined(xin, 0.05, 0.45, max_detections=100, parity=p), warmup=2) for p in (0, 1)]
+    got = []
+    for i, x in enumerate(xs):
+        xin.copy_(x)
+        g, held = graphs[i & 1]
+        g.replay()
+        torch.cuda.synchronize()
+        if i:
+            got.append((held[0].clone(), held[1].clone()))
+    r, c = m.detect_nms_flush(parity=(len(xs) - 1) & 1)
+    got.append((r.clone(), c.clone()))
+    assert len(got) == len(want)
+    for (r0, c0), (r1, c1) in zip(want, got):
+        assert torch.equal(c0, c1) and torch.equal(r0, r1)
