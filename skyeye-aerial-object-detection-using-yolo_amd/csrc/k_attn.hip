@@ -208,7 +208,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_att_t;
 
 // WIN: the groups are ws x ws windows of a [B, mh, mw] map addressed in place (token_row) and the relative position bias
 // [heads, N, N] (+ optional mask [nW, N, N]) is added to the scaled scores (WindowedSelfAttention, attention.py:377-392).
-template <int D, bool WIN>
+// The next block's K / V chunks are requested (into registers) before the current block's arithmetic and written to LDS behind the next barrier
+// (P5 TransformerLayer of the head-attention variant, 1600 tokens: 0.389 -> 0.355 ms).
+// QF: 16-query fragments per wave (a workgroup owns 64 * QF queries); per query the arithmetic does not depend on it.  QF = 2 (every K / V^T
+// fragment read feeds two MFMAs, the tiles are fetched half as often) measured 0.369 ms against 0.355 for QF = 1 -- 144 VGPRs take half the
+// waves away -- and is not instantiated (experiments/README.md).
+template <int D, bool WIN, int QF = 1>
 __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __restrict__ qkv, int ldq, __bf16* __restrict__ out, int ldo, int N,
                                                              int C, float scale, const float* __restrict__ bias, const float* __restrict__ mask,
                                                              int nW, int ws, int mh, int mw)
@@ -217,6 +222,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
     constexpr int OT = D / 16;                  // 16-channel tiles of the output
     constexpr int KROW = D * 2;                 // bytes of one K row in LDS
     constexpr int CM = (D / 8 < 8 ? D / 8 : 8) - 1;   // chunk-swizzle mask inside one K row (rows of 32 channels have 4 chunks)
+    constexpr int NCH = 64 * (D / 8) / 256;     // 16-byte chunks of a 64-key K (or V) tile per thread
     __shared__ __attribute__((aligned(16))) char kl[64 * KROW];       // K tile [64 keys][D], chunks swizzled by (key >> 1) & 7
     __shared__ __attribute__((aligned(16))) char vl[64 * KROW];       // V tile [64 keys][D], row-major; 32-byte channel pairs swizzled by the key
                                                                       // so that the transposed reads below are conflict-free
@@ -230,94 +236,122 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
         return ((((c >> 1) ^ f) << 1) | (c & 1)) << 4;
     };
     const int h = blockIdx.y, b = blockIdx.z;                          // b: image, or window when WIN
-    const int q = blockIdx.x * 64 + wave * 16 + n;                     // this lane's query
-    const bool qok = q < N;
-    const long qrow = WIN ? token_row(b, qok ? q : 0, N, ws, mh, mw) : (long)b * N + q;
-
-    u32x4_t qf[KT];                                                    // B operand of S^T: Q[q][ks*32 + g*8 .. +8]
+    int q[QF];
+    bool qok[QF];
+    long qrow[QF];
+    u32x4_t qf[QF][KT];                                                // B operand of S^T: Q[q][ks*32 + g*8 .. +8]
+    f32x4_t o[QF][OT];
+    float m[QF], l[QF];
 #pragma unroll
-    for (int ks = 0; ks < KT; ++ks)
-        qf[ks] = qok ? *reinterpret_cast<const u32x4_t*>(qkv + qrow * ldq + h * D + ks * 32 + g * 8) : u32x4_t{0u, 0u, 0u, 0u};
-
-    f32x4_t o[OT];
+    for (int f = 0; f < QF; ++f) {
+        q[f] = blockIdx.x * (64 * QF) + wave * (16 * QF) + f * 16 + n;   // this lane's queries
+        qok[f] = q[f] < N;
+        qrow[f] = WIN ? token_row(b, qok[f] ? q[f] : 0, N, ws, mh, mw) : (long)b * N + q[f];
 #pragma unroll
-    for (int t = 0; t < OT; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.0f;
+        for (int ks = 0; ks < KT; ++ks)
+            qf[f][ks] = qok[f] ? *reinterpret_cast<const u32x4_t*>(qkv + qrow[f] * ldq + h * D + ks * 32 + g * 8) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < OT; ++t) o[f][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        m[f] = -INFINITY;
+        l[f] = 0.0f;
+    }
     const float sl2 = scale * 1.4426950408889634f;                     // exp(x * scale) = exp2(x * scale * log2 e)
 
+    // K / V chunks of one 64-key block: thread -> chunks idx = tid + i * 256, key = idx / (D / 8), c = idx % (D / 8)
+    u32x4_t kreg[NCH], vreg[NCH];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int key = idx / (D / 8), c = idx - key * (D / 8);
+            const int j = j0 + key;
+            kreg[i] = u32x4_t{0u, 0u, 0u, 0u};
+            vreg[i] = kreg[i];
+            if (j < N) {
+                const long jrow = WIN ? token_row(b, j, N, ws, mh, mw) : (long)b * N + j;
+                kreg[i] = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + C + h * D + c * 8);
+                vreg[i] = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + 2 * C + h * D + c * 8);
+            }
+        }
+    };
+    fetch(0);
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();                                               // previous tiles are consumed
         // ---- stage K (row-major, swizzled) and V^T (permuted key slots) ----
-        for (int idx = tid; idx < 64 * (D / 8); idx += 256) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
             const int key = idx / (D / 8), c = idx - key * (D / 8);    // 16-byte chunk c (8 channels) of key row `key`
-            const int j = j0 + key;
-            u32x4_t kv = u32x4_t{0u, 0u, 0u, 0u}, vv = kv;
-            if (j < N) {
-                const long jrow = WIN ? token_row(b, j, N, ws, mh, mw) : (long)b * N + j;
-                kv = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + C + h * D + c * 8);
-                vv = *reinterpret_cast<const u32x4_t*>(qkv + jrow * ldq + 2 * C + h * D + c * 8);
-            }
-            *reinterpret_cast<u32x4_t*>(kl + key * KROW + (((c & ~CM) | ((c ^ (key >> 1)) & CM)) << 4)) = kv;
-            *reinterpret_cast<u32x4_t*>(vl + key * KROW + vchunk(c, key)) = vv;
+            *reinterpret_cast<u32x4_t*>(kl + key * KROW + (((c & ~CM) | ((c ^ (key >> 1)) & CM)) << 4)) = kreg[i];
+            *reinterpret_cast<u32x4_t*>(vl + key * KROW + vchunk(c, key)) = vreg[i];
         }
         __syncthreads();
+        if (j0 + 64 < N) fetch(j0 + 64);                               // flies under this block's arithmetic
         // ---- S^T tiles: keys 16T + 4g + r of this 64-key block x query n ----
-        f32x4_t sT[4];
+        f32x4_t sT[QF][4];
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            sT[T] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < QF; ++f) sT[f][T] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KT; ++ks) {
                 const int key = T * 16 + n;                            // A operand row of this lane
                 const int c = ks * 4 + g;
                 const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(kl + key * KROW + (((c & ~CM) | ((c ^ (key >> 1)) & CM)) << 4));
-                sT[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, kf), __builtin_bit_cast(bf16x8_att_t, qf[ks]), sT[T], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    sT[f][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, kf), __builtin_bit_cast(bf16x8_att_t, qf[f][ks]), sT[f][T], 0, 0, 0);
             }
         }
         // ---- online softmax for query n (log2 domain) ----
-        float bm = -INFINITY;
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+        for (int f = 0; f < QF; ++f) {
+            float bm = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = j0 + T * 16 + 4 * g + r;
-                float add = 0.0f;                                      // bias[h][query][key] (+ mask[window % nW][query][key])
-                if (WIN && qok && key < N) {
-                    if (bias) add = bias[((long)h * N + q) * N + key];
-                    if (mask) add += mask[((long)(b % nW) * N + q) * N + key];
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = j0 + T * 16 + 4 * g + r;
+                    float add = 0.0f;                                  // bias[h][query][key] (+ mask[window % nW][query][key])
+                    if (WIN && qok[f] && key < N) {
+                        if (bias) add = bias[((long)h * N + q[f]) * N + key];
+                        if (mask) add += mask[((long)(b % nW) * N + q[f]) * N + key];
+                    }
+                    sT[f][T][r] = key < N ? __builtin_fmaf(sT[f][T][r], sl2, add * 1.4426950408889634f) : -INFINITY;
+                    bm = sT[f][T][r] > bm ? sT[f][T][r] : bm;
                 }
-                sT[T][r] = key < N ? __builtin_fmaf(sT[T][r], sl2, add * 1.4426950408889634f) : -INFINITY;
-                bm = sT[T][r] > bm ? sT[T][r] : bm;
-            }
-        bm = fmaxf(bm, __shfl_xor(bm, 16));
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float mn = bm > m ? bm : m;
-        const float corr = __builtin_amdgcn_exp2f(m - mn);             // m = -inf on the first block: exp2(-inf) = 0
-        float bs = 0.0f;
+            bm = fmaxf(bm, __shfl_xor(bm, 16));
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float mn = bm > m[f] ? bm : m[f];
+            const float corr = __builtin_amdgcn_exp2f(m[f] - mn);      // m = -inf on the first block: exp2(-inf) = 0
+            float bs = 0.0f;
 #pragma unroll
-        for (int T = 0; T < 4; ++T)
+            for (int T = 0; T < 4; ++T)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sT[T][r] = __builtin_amdgcn_exp2f(sT[T][r] - mn);
-                bs += sT[T][r];
-            }
-        bs += __shfl_xor(bs, 16);
-        bs += __shfl_xor(bs, 32);
-        l = l * corr + bs;
-        m = mn;
+                for (int r = 0; r < 4; ++r) {
+                    sT[f][T][r] = __builtin_amdgcn_exp2f(sT[f][T][r] - mn);
+                    bs += sT[f][T][r];
+                }
+            bs += __shfl_xor(bs, 16);
+            bs += __shfl_xor(bs, 32);
+            l[f] = l[f] * corr + bs;
+            m[f] = mn;
 #pragma unroll
-        for (int t = 0; t < OT; ++t)
+            for (int t = 0; t < OT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[t][r] *= corr;
+                for (int r = 0; r < 4; ++r) o[f][t][r] *= corr;
+        }
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4_t pf;                                                // this lane's probabilities of tiles 2ks, 2ks+1 as 8 bf16
+            u32x4_t pf[QF];                                            // this lane's probabilities of tiles 2ks, 2ks+1 as 8 bf16
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4_t& src = sT[2 * ks + (e >> 1)];
-                pf[e] = pack_bf16x2(src[(e & 1) * 2], src[(e & 1) * 2 + 1]);
-            }
+            for (int f = 0; f < QF; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4_t& src = sT[f][2 * ks + (e >> 1)];
+                    pf[f][e] = pack_bf16x2(src[(e & 1) * 2], src[(e & 1) * 2 + 1]);
+                }
 #pragma unroll
             for (int t = 0; t < OT; ++t) {
                 // A operand (channel t*16 + n, the 8 keys of this lane's K-group): two transposed reads of 4 keys x 16 channels.  Lane
@@ -332,20 +366,24 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const __bf16* __res
                     vf[2 * e] = u.x;
                     vf[2 * e + 1] = u.y;
                 }
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, vf), __builtin_bit_cast(bf16x8_att_t, pf), o[t], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    o[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_att_t, vf), __builtin_bit_cast(bf16x8_att_t, pf[f]), o[f][t], 0, 0, 0);
             }
         }
     }
-    if (qok) {
-        const float inv = 1.0f / l;
 #pragma unroll
-        for (int t = 0; t < OT; ++t) {
-            uint2 w;
-            w.x = pack_bf16x2(o[t][0] * inv, o[t][1] * inv);
-            w.y = pack_bf16x2(o[t][2] * inv, o[t][3] * inv);
-            *reinterpret_cast<uint2*>(out + qrow * ldo + h * D + t * 16 + 4 * g) = w;
+    for (int f = 0; f < QF; ++f)
+        if (qok[f]) {
+            const float inv = 1.0f / l[f];
+#pragma unroll
+            for (int t = 0; t < OT; ++t) {
+                uint2 w;
+                w.x = pack_bf16x2(o[f][t][0] * inv, o[f][t][1] * inv);
+                w.y = pack_bf16x2(o[f][t][2] * inv, o[f][t][3] * inv);
+                *reinterpret_cast<uint2*>(out + qrow[f] * ldo + h * D + t * 16 + 4 * g) = w;
+            }
         }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ 8 x 8 window core
@@ -538,9 +576,9 @@ hipError_t launch_attention(int dtype, const void* qkv, int ldq, void* out, int 
         return hipGetLastError();
     }
     if (dtype != 0 && !no_mfma && N >= 64 && (D == 32 || D == 64 || D == 128) && ldq % 8 == 0 && ldo % 4 == 0 && C % 8 == 0) {
-        const dim3 grid((N + 63) / 64, heads, G);
         const bool win = ws > 0 || bias || mask;
-#define SKY_FLASH(DD, WW) hipLaunchKernelGGL((attention_mfma_kernel<DD, WW>), grid, dim3(256), 0, s, (const __bf16*)qkv, ldq, (__bf16*)out, ldo, N, C, \
+        const dim3 grid((N + 63) / 64, heads, G);
+#define SKY_FLASH(DD, WW) hipLaunchKernelGGL((attention_mfma_kernel<DD, WW, 1>), grid, dim3(256), 0, s, (const __bf16*)qkv, ldq, (__bf16*)out, ldo, N, C, \
                                              scale, bias, mask, nW > 0 ? nW : 1, ws, mh, mw)
         if (D == 32) { if (win) SKY_FLASH(32, true); else SKY_FLASH(32, false); }
         else if (D == 64) { if (win) SKY_FLASH(64, true); else SKY_FLASH(64, false); }
