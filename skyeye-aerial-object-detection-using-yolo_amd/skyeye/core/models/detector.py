@@ -244,7 +244,9 @@ class SkyEyeDetector(NativeModule):
                 self.__dict__["_out_slot"] = 0
         prev = st["pending"] if parity is None else st.get(("det", 1 - p))
         result = None
-        if prev is not None and prev.shape[0] == B:
+        if prev is not None and prev.shape[0] != B:                            # batch size changed: the previous batch's NMS into fresh tensors
+            result = nms_raw(prev, conf_threshold, iou_threshold, max_detections=max_detections, **nms_kw)
+        elif prev is not None:
             ck = ("nms_pipe", B, int(max_detections), 1 - p)
             bufs = self._out_cache.get(ck)
             if bufs is None:
@@ -259,7 +261,7 @@ class SkyEyeDetector(NativeModule):
             det = self._run([xi], skip=(1, 2, 3))[0]
         finally:
             self.__dict__["_out_slot"] = 0
-        if result is not None:
+        if result is not None and prev.shape[0] == B:
             cur.wait_stream(side)                                              # join
         st[("det", p)] = det
         st["pending"] = det
