@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--with-raw", action="store_true", help="also write the three raw detection levels (the reference's second return value)")
     ap.add_argument("--streams", type=int, default=2, help="run the batch as this many equal slices on parallel branches of the captured graph (each "
                     "slice has its own plan); 1 = the whole batch through one plan")
+    ap.add_argument("--slices", default="", help="explicit slice sizes for the parallel streams, e.g. 20,12 (default: --streams equal slices)")
     ap.add_argument("--no-pipeline", action="store_true", help="NMS of a batch strictly behind its own forward pass (default: the NMS of batch k runs beside the "
                     "forward pass of batch k + 1, SkyEyeDetector.detect_nms_pipelined; every batch's NMS is inside the timed region)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of configs 3, 4 (shard), 5 (shard) behind the headline measurement")
@@ -194,7 +195,9 @@ def main():
         calibrate_objectness(model, x, 0.01, a.conf)
         model.reuse_output_buffers(True)
 
-        if a.streams > 1 and precision != "fp8":
+        if a.slices and precision != "fp8":
+            model.parallel_slices([int(v) for v in a.slices.split(",")])
+        elif a.streams > 1 and precision != "fp8":
             model.parallel_slices(a.streams)                     # the batch as equal slices on parallel HIP streams, one plan each
 
         def local_step():

@@ -182,6 +182,14 @@ class NativeModule(nn.Module):
         gaps between dependent launches (skyeye_s bf16 B = 32 @1280: +3.6 % with two slices, measured; four lose again).  Works
         under ``capture_graph`` (fork / join by stream events).  Applies to batch-first modules whose batch divides by n; fp8 plans
         take part only when ``calibrate()`` gave them common calibration frames.  ``n = 1`` switches it off (the default)."""
+        if isinstance(n, (list, tuple)):                       # explicit slice sizes, e.g. (20, 12): batches of exactly sum(n) frames are sliced that way
+            sizes = tuple(int(v) for v in n)
+            if len(sizes) < 1 or any(v < 1 for v in sizes):
+                raise ValueError("parallel_slices: slice sizes must be positive")
+            self.__dict__["_slice_sizes"] = sizes if len(sizes) > 1 else None
+            self.__dict__["_slices"] = len(sizes)
+            return self
+        self.__dict__["_slice_sizes"] = None
         self.__dict__["_slices"] = max(1, int(n))
         return self
 
@@ -339,7 +347,13 @@ class NativeModule(nn.Module):
         return list(outs)
 
     def _sliceable(self, inputs, nsl):
-        if any(t.dim() < 2 or t.shape[0] != inputs[0].shape[0] for t in inputs) or inputs[0].shape[0] % nsl or inputs[0].shape[0] < 2 * nsl:
+        sizes = self.__dict__.get("_slice_sizes")
+        if any(t.dim() < 2 or t.shape[0] != inputs[0].shape[0] for t in inputs):
+            return False
+        if sizes is not None:
+            if sum(sizes) != inputs[0].shape[0]:
+                return False
+        elif inputs[0].shape[0] % nsl or inputs[0].shape[0] < 2 * nsl:
             return False
         if self._resolved_precision() == "fp8" and not self.__dict__.get("_calib_inputs"):
             return False                # every slice would calibrate itself on its own frames: other scales than the whole batch
@@ -350,16 +364,18 @@ class NativeModule(nn.Module):
         ``post(i, lo, hi, out_views)``: more work of slice i (its NMS) enqueued on its stream before the join."""
         dev = inputs[0].device
         B = inputs[0].shape[0]
-        b = B // nsl
+        sizes = self.__dict__.get("_slice_sizes") or (B // nsl,) * nsl
+        lo = [sum(sizes[:i]) for i in range(nsl)]
+        hi = [lo[i] + sizes[i] for i in range(nsl)]
         st = self.__dict__.setdefault("_slice_streams", {})
         streams = st.get(dev.index or 0)
         if streams is None or len(streams) != nsl:
             streams = st[dev.index or 0] = [torch.cuda.Stream(device=dev) for _ in range(nsl)]
-        parts = [[t[i * b:(i + 1) * b] for t in inputs] for i in range(nsl)]
+        parts = [[t[lo[i]:hi[i]] for t in inputs] for i in range(nsl)]
         ents = [self._engine_entry(parts[i], extra_cfg, slot=i + 1) for i in range(nsl)]       # (plans are made on the caller's stream)
         shapes = [(B,) + tuple(sh[1:]) for sh in ents[0][1].output_shapes()]
         cache = self._out_cache
-        ckey = ("sliced", self.__dict__.get("_out_slot", 0), ents[0][0])
+        ckey = ("sliced", (self.__dict__.get("_out_slot", 0), sizes), ents[0][0])
         outs = cache.get(ckey) if cache is not None else None
         if outs is None or any((o is None) != (i in skip) for i, o in enumerate(outs)):
             outs = [None if i in skip else torch.empty(sh, dtype=torch.float32, device=dev) for i, sh in enumerate(shapes)]
@@ -370,10 +386,10 @@ class NativeModule(nn.Module):
             streams[i].wait_stream(cur)                                         # fork (capturable)
             with torch.cuda.stream(streams[i]):
                 ents[i][1].forward([N.buffer_from_tensor(t) for t in parts[i]],
-                                   [N.null_buffer() if o is None else N.buffer_from_tensor(o[i * b:(i + 1) * b]) for o in outs],
+                                   [N.null_buffer() if o is None else N.buffer_from_tensor(o[lo[i]:hi[i]]) for o in outs],
                                    streams[i].cuda_stream)
                 if post is not None:
-                    post(i, i * b, (i + 1) * b, [None if o is None else o[i * b:(i + 1) * b] for o in outs])
+                    post(i, lo[i], hi[i], [None if o is None else o[lo[i]:hi[i]] for o in outs])
         for s_ in streams:
             cur.wait_stream(s_)                                                 # join: the caller's stream owns the results again
         return list(outs)

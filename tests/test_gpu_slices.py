@@ -110,3 +110,17 @@ def test_detect_nms_pipelined_equals_detect_nms_per_batch():
     assert len(got) == len(want)
     for (r0, c0), (r1, c1) in zip(want, got):
         assert torch.equal(c0, c1) and torch.equal(r0, r1)
+
+
+def test_unequal_slices_equal_whole_batch():
+    """parallel_slices((5, 3)): explicit slice sizes (batches of exactly their sum are sliced that way) -- bit-identical again."""
+    x = torch.from_numpy(seeded_scene(8, 256, 320, 33)).cuda()
+    det0, raw0 = _model()(x)
+    sl = _model().parallel_slices((5, 3))
+    det1, raw1 = sl(x)
+    assert torch.equal(det0, det1) and all(torch.equal(a, b) for a, b in zip(raw0, raw1))
+    r0, c0 = nms_raw(det0, 0.05, 0.45, max_detections=100)
+    r1, c1 = sl.detect_nms(x, 0.05, 0.45, max_detections=100)
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+    y = torch.from_numpy(seeded_scene(6, 256, 320, 34)).cuda()          # another batch size: not sliced, still right
+    assert torch.equal(_model()(y)[0], sl(y)[0])
