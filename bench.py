@@ -229,8 +229,9 @@ def main():
             graphs = None if a.no_graph else [capture_graph(lambda p=p: pipe_step(p), warmup=2) for p in (0, 1)]
             # two steps (parity 0 then 1) as ONE replay where nothing happens between them on the host: one graph-launch gap per two batches
             pair = None
+            npair = max(1, int(os.environ.get("SKY_BENCH_PAIRS", "2")))          # even / odd pairs per replay
             if graphs is not None and world == 1 and not os.environ.get("SKY_BENCH_NO_PAIR"):
-                pair = capture_graph(lambda: (pipe_step(0), pipe_step(1)), warmup=1)
+                pair = capture_graph(lambda: tuple(pipe_step(i & 1) for i in range(2 * npair)), warmup=1)
             state = {"k": 0}
 
             def step():
@@ -249,11 +250,11 @@ def main():
                 """n steps; pairs of (even, odd) steps as one replay where possible.  Returns the last step's result (the batch before it)."""
                 res = None
                 while n > 0:
-                    if pair is not None and n >= 2 and not (state["k"] & 1):
+                    if pair is not None and n >= 2 * npair and not (state["k"] & 1):
                         pair[0].replay()
-                        res = pair[1][1]
-                        state["k"] += 2
-                        n -= 2
+                        res = pair[1][-1]
+                        state["k"] += 2 * npair
+                        n -= 2 * npair
                     else:
                         res = step()
                         n -= 1
@@ -267,6 +268,7 @@ def main():
         else:
             step = sync_step
             pair = None
+            npair = 1
 
             def finish():
                 return None
@@ -290,7 +292,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dict(model=model, P=P, x=x, frames_np=frames_np, step=sync_step, graph=graph, dt=dt, counts=counts, pipelined=pipelined,
-                    steps_per_replay=2 if (pipelined and pair is not None) else 1)
+                    steps_per_replay=2 * npair if (pipelined and pair is not None) else 1)
 
     def fence():
         if world > 1:
