@@ -152,6 +152,11 @@ typedef struct {
                                  * stage of tiled inference, whose input is the survivors of the per-tile NMS */
     int32_t n_classes;          /* length of `classes`, 0 = no filter */
     int32_t classes[64];
+    /* round 4 (struct_size tells the library whether the caller knows them; a shorter struct means 0, 0): output strides, so that
+     * the rows and the count of an image can land directly in a caller's exchange buffer (skyeye/distributed.py: BoxExchange --
+     * one block of max_detections * 7 floats + the count per image, sent by ONE all-gather without repacking). */
+    int32_t out_image_stride;   /* floats between the row blocks of consecutive images; 0 = max_detections * 7 (dense) */
+    int32_t counts_stride;      /* int32 elements between consecutive counts; 0 = 1 (dense) */
 } sky_nms_params;
 
 typedef struct sky_handle sky_handle;
@@ -190,7 +195,12 @@ int sky_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, int n_out
  * batch size, same C, H, W) and give every fp8 workspace tensor the scale max|x| / 448.  sky_forward on an fp8 plan fails with
  * SKY_ERR_STATE until this (or sky_scales_write) has been called.  Synchronises `stream`.  The scales belong to the plan:
  * sky_num_scales / sky_scales_read / sky_scales_write save and restore them (one float per workspace buffer, 1 for non-fp8 ones),
- * sky_packed_scales returns the per-output-channel weight scales of packed convolution i (ones for bf16 / fp32 weights). */
+ * sky_packed_scales returns the per-output-channel scales of packed convolution i: real weight = stored weight * scale.
+ *   fp8:  the weight scale of the row (max |w| / 448); the bias rows are stored unscaled.
+ *   bf16: ln 2 for the rows of a SiLU convolution -- the bf16 engine keeps those layers in the exp2 domain (weights AND bias are
+ *         stored times log2 e, the activation is v' * rcp(fma(exp2(-v'), log2 e, log2 e)), csrc/conv_frag.h) so for them the real
+ *         bias = stored bias * scale too; 1 for layers without SiLU.
+ *   fp32: 1. */
 int sky_calibrate(sky_handle* h, int n_inputs, const sky_buffer* inputs, void* stream);
 int sky_num_scales(const sky_handle* h);
 int sky_scales_read(sky_handle* h, float* scales_host, int n);
@@ -212,7 +222,8 @@ int sky_nms_fetch(sky_handle* h, const int32_t* counts_dev, int B, int32_t* coun
 /* Export of the engine's own weight file (the reference's export.py is empty and fuse_conv_and_bn,
  * general imports at utils/__init__.py:22-25, is undefined): the convolution weights exactly as the kernels read them --
  * BatchNorm folded (w * gamma / sqrt(var + 1e-5), bias = beta - mean * scale, blocks.py:39-41 fused_forward), K ordered
- * (ky, kx, cin) and padded to `kpad`, rows padded to the N tile, element type of the engine -- plus the fp32 bias rows.
+ * (ky, kx, cin) and padded to `kpad`, rows padded to the N tile, element type of the engine -- plus the fp32 bias rows; times the
+ * per-row factor sky_packed_scales reports they are the folded fp32 values (fp8 rows, exp2-domain rows of the bf16 engine).
  * Valid after sky_plan.  sky_packed_read copies to host buffers (either may be NULL). */
 typedef struct sky_packed_desc {
     char name[128];        /* state-dict name of the source weight (the first one for fused GEMMs such as cv1|cv2) */

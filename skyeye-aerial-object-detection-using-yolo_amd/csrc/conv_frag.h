@@ -56,7 +56,23 @@ struct S1<__bf16> {
     // __expf: the library form wraps v_exp_f32 in a denormal-range guard (compare, two selects, a scale: 4 more VALU instructions per
     // value), and the activation, not the MFMA, is the longer pipe of the small-K layers (45 of ~63 VALU cycles per output value of a
     // 64-channel 3x3).  Below 2^-126 the raw result flushes to 0 -> 1 + 0, above 2^127 it is +inf -> rcp = 0 -> v * 0: both right.
-    static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+    // EXP2 DOMAIN (round 4): the bf16 engine packs the weights and the bias of every SiLU convolution times log2(e) (engine.cpp:
+    // pack_conv), so the accumulator + bias is v' = v log2 e and
+    //     SiLU(v) = v / (1 + e^-v) = v' / (log2 e (1 + 2^-v')) = v' * rcp(fma(exp2(-v'), log2 e, log2 e)):
+    // exp (8 issue cycles) + fma (4) + rcp (8) + mul (4) instead of mul + exp + add + rcp + mul -- the negation is an input modifier.
+    // gate(v') = sigmoid(v) / log2 e: SiLU(v) = v' * gate(v'); kernels that write the activation's last multiplication together
+    // with a residual add as one fma (k_csp_stage.hip) take the gate alone
+    static __device__ __forceinline__ float gate(float v)
+    {
+#ifdef SKY_PRE_C
+        // experiment (tools/pre_scale_ab.sh): the pre-activation held times an arbitrary c instead of log2 e -- one more multiplication,
+        // another rounding realisation of every weight; measures how much the reduced-precision agreement rates move with that alone
+        return __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(v * (float)(-1.4426950408889634 / (SKY_PRE_C))), (float)(SKY_PRE_C), (float)(SKY_PRE_C)));
+#else
+        return __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-v), 1.4426950408889634f, 1.4426950408889634f));
+#endif
+    }
+    static __device__ __forceinline__ float silu(float v) { return v * gate(v); }
 };
 template <>
 struct S1<float> {

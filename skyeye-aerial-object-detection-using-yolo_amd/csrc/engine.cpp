@@ -16,6 +16,7 @@
 #include "sky_kernels.h"
 #include "build_hash.h"
 
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -116,6 +117,7 @@ struct DevConv {
     float* mult = nullptr;           // fp8: per-output-channel input scale x weight scale (device, [rows]); set by apply_scales
     std::vector<float> w_scale;      // fp8: per-output-channel weight scale (host, [rows])
     int cdt = 0;                     // element type of the packed weights
+    float pre = 1.0f;                // bf16 SiLU layers: log2(e), the factor weights and bias were packed with (exp2-domain activation)
     int Kpad = 0;
     size_t bytes = 0;
     // description for sky_packed_* (export of the engine's own weight file)
@@ -345,10 +347,19 @@ struct Ctx {
         std::string bn;      // bn prefix ("" = none)
         std::string bias;    // bias name ("" = none)
     };
-    int pack_conv(const std::vector<ConvSrc>& srcs, int cin_real, int cin_store, int ks, int cdt = -1)
+    // act: the activation the kernels apply to this convolution.  bf16 + SiLU: the rows and the bias are packed in the EXP2 DOMAIN,
+    // i.e. times log2(e) -- the accumulator then holds v' = v log2 e and SiLU is v' * rcp(fma(exp2(-v'), log2 e, log2 e)) = v / (1 + e^-v)
+    // (conv_frag.h: S1<__bf16>::silu), one VALU multiplication per output value less.  The scaling happens in double before the
+    // one bf16 rounding of a weight: same relative rounding error as the unscaled weight's.
+    int pack_conv(const std::vector<ConvSrc>& srcs, int cin_real, int cin_store, int ks, int cdt = -1, int act = ACT_NONE)
     {
         if (!emit) return -1;
         if (cdt < 0) cdt = e.dtype;
+#ifdef SKY_PRE_C
+        const double pre = (cdt == SKY_BF16 && act == ACT_SILU) ? (double)(SKY_PRE_C) : 1.0;      // experiment, see conv_frag.h
+#else
+        const double pre = (cdt == SKY_BF16 && act == ACT_SILU) ? 1.4426950408889634 : 1.0;
+#endif
         int cout = 0;
         for (auto& s : srcs) cout += (int)W(s.wname).shape[0];
         const int taps = ks * ks;
@@ -371,17 +382,19 @@ struct Ctx {
                     shift = b - mu * scale;
                 }
                 if (!s.bias.empty()) shift += W(s.bias).data[co] * scale;
-                bias[row0 + co] = shift;
+                bias[row0 + co] = (float)((double)shift * pre);
                 float* dst = packed.data() + (size_t)(row0 + co) * Kpad;
                 for (int ci = 0; ci < cin_real; ++ci)
                     for (int t = 0; t < taps; ++t)
-                        dst[t * cin_store + ci] = w.data[((size_t)co * cin_real + ci) * taps + t] * scale;
+                        dst[t * cin_store + ci] = pre == 1.0 ? w.data[((size_t)co * cin_real + ci) * taps + t] * scale
+                                                             : (float)((double)(w.data[((size_t)co * cin_real + ci) * taps + t] * scale) * pre);
             }
             row0 += co_n;
         }
         DevConv d;
         d.Kpad = Kpad;
         d.cdt = cdt;
+        d.pre = (float)pre;
         d.bytes = packed.size() * dtype_size(cdt);
         d.rows = (int)rows; d.cout = cout; d.ks = ks; d.cin = cin_store;
         d.name = srcs.empty() ? std::string() : srcs[0].wname;
@@ -463,7 +476,7 @@ static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cou
     op.cin = cin; op.cout = cout; op.ks = k; op.stride = s; op.act = act ? ACT_SILU : ACT_NONE; op.up2 = o.up2 ? 1 : 0;
     op.Ho = Ho; op.Wo = Wo;
     op.cdt = x.dt;
-    op.wid = c.pack_conv({{p + "conv.weight", p + "bn.", ""}}, cin_real, cin, k, op.cdt);
+    op.wid = c.pack_conv({{p + "conv.weight", p + "bn.", ""}}, cin_real, cin, k, op.cdt, op.act);
     op.flops = 2.0 * x.B * Ho * Wo * (double)cout * k * k * cin_real;
     c.push(op);
     return y;
@@ -504,8 +517,8 @@ static TV bottleneck(Ctx& c, const std::string& p, const TV& x, int cin, int cou
         op.cin = hidden; op.cout = cout; op.ks = 3; op.stride = 1; op.act = ACT_SILU;
         op.Ho = x.H; op.Wo = x.W;
         op.cdt = x.dt;
-        op.wid1 = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}}, cin, cin, 1, op.cdt);
-        op.wid = c.pack_conv({{p + "cv2.conv.weight", p + "cv2.bn.", ""}}, hidden, hidden, 3, op.cdt);
+        op.wid1 = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}}, cin, cin, 1, op.cdt, ACT_SILU);
+        op.wid = c.pack_conv({{p + "cv2.conv.weight", p + "cv2.bn.", ""}}, hidden, hidden, 3, op.cdt, op.act);
         op.c1_res = shortcut && cin == cout;
         op.flops = 2.0 * x.B * x.H * x.W * ((double)hidden * cin + (double)cout * 9 * hidden);
         c.push(op);
@@ -544,7 +557,7 @@ static TV csp(Ctx& c, const std::string& p, const TV& x, int cin, int cout, int 
         op.cin = cin; op.cout = 2 * h; op.ks = 1; op.stride = 1; op.act = ACT_SILU;
         op.Ho = x.H; op.Wo = x.W;
         op.cdt = x.dt;
-        op.wid = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}, {p + "cv2.conv.weight", p + "cv2.bn.", ""}}, cin, cin, 1, op.cdt);
+        op.wid = c.pack_conv({{p + "cv1.conv.weight", p + "cv1.bn.", ""}, {p + "cv2.conv.weight", p + "cv2.bn.", ""}}, cin, cin, 1, op.cdt, op.act);
         op.flops = 2.0 * x.B * x.H * x.W * (double)(2 * h) * cin;
         c.push(op);
     }
@@ -684,7 +697,7 @@ static TV linear(Ctx& c, const std::string& wname, const std::string& bname, con
     op.cin = cin; op.cout = cout; op.ks = 1; op.stride = 1; op.act = act;
     op.Ho = x.H; op.Wo = x.W;
     op.cdt = x.dt;
-    op.wid = c.pack_conv({{wname, "", bname}}, cin, cin, 1, op.cdt);
+    op.wid = c.pack_conv({{wname, "", bname}}, cin, cin, 1, op.cdt, op.act);
     op.flops = 2.0 * x.B * x.H * x.W * (double)cout * cin;
     c.push(op);
     return y;
@@ -1736,6 +1749,7 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_CSP_STAGE")) o |= OPT_NO_CSP_STAGE;
     if (env("SKY_NO_HEAD_STREAM")) o |= OPT_NO_HEAD_STREAM;
     if (env("SKY_NO_BNECK128")) o |= OPT_NO_BNECK128;
+    if (const char* v = env("SKY_BNECK128")) o |= v[0] == 's' ? OPT_BNECK128_SOLO : 0u;
     if (env("SKY_NO_DEEP3X3")) o |= OPT_NO_DEEP3X3;
     if (env("SKY_NO_IN2")) o |= OPT_NO_IN2;
     if (env("SKY_NO_CV3_HEAD")) o |= OPT_NO_CV3_HEAD;
@@ -2137,7 +2151,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? (op.in2_cin ? " +res in2" : " +res") : (op.in2_cin ? " in2" : ""), op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 3256 ? "gemm1x1/" : op.variant == 7128 ? "bneck" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 3256 ? "gemm1x1/" : op.variant == 7128 ? "bneck" : op.variant == 7256 ? "bneck128x2/" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)
@@ -2216,7 +2230,8 @@ int sky_packed_scales(sky_handle* h, int i, float* scales_host, size_t count)
         if (i < 0 || i >= (int)h->e.convs.size() || !scales_host) throw Error(SKY_ERR_INVALID, "sky_packed_scales: bad argument");
         const DevConv& d = h->e.convs[i];
         if (count < (size_t)d.rows) throw Error(SKY_ERR_INVALID, "sky_packed_scales: buffer too small");
-        for (int r = 0; r < d.rows; ++r) scales_host[r] = d.w_scale.empty() ? 1.0f : d.w_scale[r];
+        // real weight = stored * scale: fp8 rows carry their own scale, exp2-domain rows of the bf16 engine 1 / log2 e (pack_conv)
+        for (int r = 0; r < d.rows; ++r) scales_host[r] = d.w_scale.empty() ? (float)(1.0 / (double)d.pre) : d.w_scale[r];
     });
 }
 
@@ -2270,7 +2285,10 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
     if (!h) return SKY_ERR_INVALID;
     return guarded(h, [&] {
         if (!det || !p || !out || !counts) throw Error(SKY_ERR_INVALID, "sky_nms: null argument");
-        if (p->struct_size != sizeof(sky_nms_params)) throw Error(SKY_ERR_INVALID, "sky_nms: sky_nms_params size mismatch (ABI)");
+        // the round-3 struct ends in front of out_image_stride: a caller built against it gets dense outputs
+        const bool has_strides = p->struct_size == sizeof(sky_nms_params);
+        if (!has_strides && p->struct_size != offsetof(sky_nms_params, out_image_stride))
+            throw Error(SKY_ERR_INVALID, "sky_nms: sky_nms_params size mismatch (ABI)");
         if (B < 1 || N < 1 || nc < 1) throw Error(SKY_ERR_SHAPE, "sky_nms: bad geometry");
         if (p->max_detections < 1 || p->max_detections > 4096) throw Error(SKY_ERR_INVALID, "sky_nms: max_detections must be in [1, 4096]");
         if (p->n_classes > 64) throw Error(SKY_ERR_INVALID, "sky_nms: at most 64 class filters");
@@ -2286,6 +2304,10 @@ int sky_nms(sky_handle* h, const float* det, int B, int N, int nc, const sky_nms
         a.n_classes = p->n_classes;
         for (int i = 0; i < p->n_classes; ++i) a.classes[i] = p->classes[i];
         a.out = out; a.counts = counts;
+        a.out_stride = has_strides && p->out_image_stride ? p->out_image_stride : (long)p->max_detections * 7;
+        a.counts_stride = has_strides && p->counts_stride ? p->counts_stride : 1;
+        if (a.out_stride < (long)p->max_detections * 7 || a.counts_stride < 1)
+            throw Error(SKY_ERR_INVALID, "sky_nms: out_image_stride below max_detections * 7 or counts_stride below 1");
         long cap = 0;
         const size_t need = nms_workspace_bytes(B, N, nc, a.multi_label, &cap);
         if (need > h->e.nms_ws_bytes) {

@@ -25,9 +25,11 @@
 
 namespace sky {
 
+// T = the element type of the weights: the bf16 engine's SiLU layers are packed in the exp2 domain (conv_frag.h: S1<__bf16>::silu)
+template <typename T>
 __device__ __forceinline__ float act_apply(float v, int act)
 {
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_SILU) return sizeof(T) == 2 ? S1<__bf16>::silu(v) : v / (1.0f + expf(-v));
     if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
     return v;
 }
@@ -352,7 +354,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
             float v[V];
 #pragma unroll
             for (int e = 0; e < V; ++e)
-                v[e] = act_apply((QS ? ot[ml * OP + g * V + e] * (a.mult ? a.mult[n + e] : 1.0f) : ot[ml * OP + g * V + e]) + a.bias[n + e], a.act);
+                v[e] = act_apply<T>((QS ? ot[ml * OP + g * V + e] * (a.mult ? a.mult[n + e] : 1.0f) : ot[ml * OP + g * V + e]) + a.bias[n + e], a.act);
             if (a.res) {
                 const f32x4_t r = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(a.res) + (long)m * a.ldr + n);
 #pragma unroll
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(const ConvArgs 
         float v[V];
         const float* src = ot + ml * OP + g * V;
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = act_apply((QS ? src[e] * (a.mult ? a.mult[n + e] : 1.0f) : src[e]) + a.bias[n + e], a.act);
+        for (int e = 0; e < V; ++e) v[e] = act_apply<T>((QS ? src[e] * (a.mult ? a.mult[n + e] : 1.0f) : src[e]) + a.bias[n + e], a.act);
         if (a.res) Out8<TO>::add(Out8<TO>::load(reinterpret_cast<const char*>(a.res) + ((long)m * a.ldr + n) * (long)sizeof(TO)), v, a.res_scale);
         // destination pixel(s)
         long p0 = m;

@@ -1158,7 +1158,7 @@ static bool cv1_shape_ok(int dtype, ConvArgs& a)
 {
     if (dtype != 1 || (a.out_dt >= 0 && a.out_dt != 1)) return false;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2 || a.src_mode || a.f2_w) return false;
-    if (a.Cin == 128 && a.Cout == 128) return bneck128_shape_ok(a);          // the 128-channel bottleneck kernel (k_bneck.hip)
+    if (a.Cin == 128 && a.Cout == 128) return bneck128w_shape_ok(a) || bneck128_shape_ok(a);      // the 128-channel bottleneck kernels (k_bneck_w.hip, k_bneck.hip)
     if (a.Cin != 64 || a.Cout != 64 || a.c1_Kpad < 64) return false;
     if (a.in_bytes == 0 || a.out_bytes == 0) return false;
     if ((long)a.Kpad * 2 < 9L * 128 || (a.opts & (OPT_HALO_OFF | OPT_NO_FUSE_CV1))) return false;
@@ -1179,6 +1179,11 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     if (a.c1_w) {       // planned as a fused bottleneck: there is no other kernel for this op
         if (!cv1_shape_ok(dtype, a)) return hipErrorInvalidValue;
         if (a.Cin == 128) {
+            if (bneck128w_shape_ok(a)) {                      // two 4-wave workgroups per CU (round 4)
+                const hipError_t ew = launch_bneck128w(a, s);
+                if (ew == hipSuccess && variant) *variant = 7256;
+                return ew;
+            }
             const hipError_t e0 = launch_bneck128(a, s);
             if (e0 == hipSuccess && variant) *variant = 7128;
             return e0;

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float xx = e < 4 ? acc[0][i][e] + c0[e] : acc[1][i][e - 4] + c1[e - 4];
-                        const float t = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xx * -1.4426950408889634f));
+                        const float t = S1<__bf16>::gate(xx);
                         const float res = (e & 1) ? __uint_as_float(rv.a[e >> 1] & 0xffff0000u) : __uint_as_float(rv.a[e >> 1] << 16);
                         v[e] = __builtin_fmaf(xx, t, res);
                     }

@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
     int kept = 0;
     const bool nofilter = !(a.iou >= 0.0f);          // a negative threshold suppresses disjoint boxes too: no overlap filter
     const unsigned long long* keys = nms_sorted_keys(a, b);
-    float* out = a.out + (long)b * a.max_det * 7;
+    float* out = a.out + (long)b * a.out_stride;
     for (int sb = 0; sb < n && kept < a.max_det; sb += GW * 64) {
         const int k = sb + tid;
         bool alive = k < n;
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(GW * 64) nms_greedy_kernel(const NmsArgs a)
         }
         __syncthreads();   // the s_kept slots and the waves' roles start over
     }
-    if (tid == 0) a.counts[b] = kept;
+    if (tid == 0) a.counts[(long)b * a.counts_stride] = kept;
     // rows past the kept ones are defined (zeros): callers hand over uninitialised buffers and the fixed-capacity block
     // that travels through the RCCL all-gather is the same bytes on every run
     for (int i = kept * 7 + tid; i < a.max_det * 7; i += GW * 64) out[i] = 0.0f;

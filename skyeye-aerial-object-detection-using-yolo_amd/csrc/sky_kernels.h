@@ -41,6 +41,7 @@ enum PlanOpt : unsigned {
     OPT_NO_CV3_HEAD = 1u << 26,      // SKY_NO_CV3_HEAD      fpn_conv3.cv3 and detection level 0 as two launches (default: one kernel, k_head.hip)
     OPT_NO_GEMM1X1 = 1u << 27,       // SKY_NO_GEMM1X1       large-K 1x1 convolutions on the streaming kernel (default: the LDS-DMA GEMM, k_gemm1x1.hip)
     OPT_GEMM1X1_FORCE = 1u << 28,    // SKY_GEMM1X1=force    the GEMM wherever the shape is covered (default: K >= 256 and two tiles per CU or more)
+    OPT_BNECK128_SOLO = 1u << 29,    // SKY_BNECK128=solo    128-channel bottlenecks on round 3's one-workgroup-per-CU kernel (default: two 4-wave workgroups per CU, k_bneck_w.hip)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -203,6 +204,9 @@ hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 // BottleneckBlock(128, 128) as one kernel (k_bneck.hip; bf16): ConvArgs of the 3x3 with c1_w / c1_bias / c1_Kpad / c1_res set
 bool bneck128_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck128(const ConvArgs& a, hipStream_t s);
+// the same block as two 4-wave workgroups per CU on 8 x 16 tiles (k_bneck_w.hip; round 4, the default)
+bool bneck128w_shape_ok(const ConvArgs& a);
+hipError_t launch_bneck128w(const ConvArgs& a, hipStream_t s);
 
 // deep-pipelined 3x3 stride 1 for Cin a multiple of 256 (k_conv3x3_deep.hip; bf16): variant 4600 + 128
 bool conv3x3_deep_ok(int dtype, const ConvArgs& a);
@@ -274,8 +278,10 @@ struct NmsArgs {
     int agnostic, multi_label, max_det, max_nms, mode;
     int n_classes;
     int classes[64];
-    float* out;         // [B, max_det, 7]
-    int* counts;        // [B]
+    float* out;         // [B, max_det, 7], image blocks out_stride floats apart
+    int* counts;        // [B], counts_stride ints apart
+    long out_stride;    // floats between the row blocks of consecutive images (>= max_det * 7)
+    long counts_stride; // ints between consecutive counts (>= 1)
     // workspace
     int* blk_counts;    // [B, nblk]
     int* totals;        // [B]

@@ -51,7 +51,7 @@ class SkyNmsParams(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("conf_threshold", ctypes.c_float), ("iou_threshold", ctypes.c_float),
                 ("agnostic", ctypes.c_int32), ("multi_label", ctypes.c_int32), ("max_detections", ctypes.c_int32),
                 ("max_nms", ctypes.c_int32), ("max_wh", ctypes.c_float), ("mode", ctypes.c_int32), ("n_classes", ctypes.c_int32),
-                ("classes", ctypes.c_int32 * 64)]
+                ("classes", ctypes.c_int32 * 64), ("out_image_stride", ctypes.c_int32), ("counts_stride", ctypes.c_int32)]
 
 
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)

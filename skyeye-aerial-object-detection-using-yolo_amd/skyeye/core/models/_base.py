@@ -27,7 +27,7 @@ _EPOCH = [0]
 # toggles one between two calls of the same module gets a plan made under the new value
 _PLAN_SWITCHES = ("SKY_CONV_HALO", "SKY_HALO_NF8", "SKY_HALO_S2", "SKY_NO_STREAM", "SKY_NO_RING", "SKY_STREAM_OLDGRID",
                   "SKY_NO_FUSED_IMPORT", "SKY_FUSE", "SKY_NO_FUSE", "SKY_NO_SPP_PYRAMID", "SKY_ATTN_VALU", "SKY_HALO_SKIP",
-                  "SKY_NO_FUSE_CV1", "SKY_NO_STEM_DOWN", "SKY_SUBBATCH", "SKY_NO_WINATTN", "SKY_NO_CSP_STAGE", "SKY_NO_HEAD_STREAM", "SKY_HEAD_STREAM", "SKY_NO_BNECK128", "SKY_NO_DEEP3X3", "SKY_NO_IN2", "SKY_NO_CV3_HEAD", "SKY_NO_GEMM1X1", "SKY_GEMM1X1")
+                  "SKY_NO_FUSE_CV1", "SKY_NO_STEM_DOWN", "SKY_SUBBATCH", "SKY_NO_WINATTN", "SKY_NO_CSP_STAGE", "SKY_NO_HEAD_STREAM", "SKY_HEAD_STREAM", "SKY_NO_BNECK128", "SKY_BNECK128", "SKY_NO_DEEP3X3", "SKY_NO_IN2", "SKY_NO_CV3_HEAD", "SKY_NO_GEMM1X1", "SKY_GEMM1X1")
 
 
 def _bump_epoch():
@@ -220,10 +220,9 @@ class NativeModule(nn.Module):
         return self
 
     def _drop_engine(self, key):
-        """Close a plan and forget everything that was cached for it (its reusable output tensors)."""
-        ent = self._engines.pop(key, None)
-        if ent is not None:
-            ent[0].close()
+        """Forget a plan and everything that was cached for it (its reusable output tensors).  The handle is closed when its last owner
+        lets go of it (``Handle.__del__``): at once here, unless a captured hipGraph still replays into its arena (``graph._sky_keep``)."""
+        self._engines.pop(key, None)
         if self._out_cache is not None:
             for k in [k for k in self._out_cache if k == key or (isinstance(k, tuple) and len(k) == 3 and k[0] in ("slot", "sliced") and k[-1] == key)]:
                 self._out_cache.pop(k, None)
@@ -274,13 +273,20 @@ class NativeModule(nn.Module):
         key = (prec, dev.index or 0, tuple(tuple(t.shape) for t in inputs), tuple(sorted((extra_cfg or {}).items())),
                tuple(os.environ.get(k) for k in _PLAN_SWITCHES), slot)
         fp = self._weights_fingerprint()
+        pinned = self.__dict__.get("_pinned")                 # keys fetched by the call in progress (_run_sliced): never evicted by it
+        if pinned is not None:
+            pinned.add(key)
         ent = self._engines.get(key)
         if ent is not None and ent[1] == fp:
+            self._engines[key] = self._engines.pop(key)       # least recently USED first (dicts keep insertion order)
+            self._keep_for_capture(ent[0])
             return key, ent[0]
         if ent is not None:
             self._drop_engine(key)
         if len(self._engines) >= 6 + self.__dict__.get("_slices", 1):     # keep a few geometries resident (test-time augmentation plans three)
-            self._drop_engine(next(iter(self._engines)))  # the oldest plan goes first
+            victim = next((k for k in self._engines if pinned is None or k not in pinned), None)
+            if victim is not None:
+                self._drop_engine(victim)                     # the least recently used plan goes first
         cfg = dict(self._sky_config())
         cfg.update(extra_cfg or {})
         h = N.Handle(N.make_config(self._sky_module, dtype=N.DTYPES[prec], device=dev.index or 0, **cfg))
@@ -294,20 +300,31 @@ class NativeModule(nn.Module):
                 cal = inputs                       # self-calibration on the first batch of this geometry
             h.calibrate([N.buffer_from_tensor(t) for t in cal], torch.cuda.current_stream(dev).cuda_stream)
         self._engines[key] = (h, fp)
+        self._keep_for_capture(h)
         return key, h
+
+    @staticmethod
+    def _keep_for_capture(h):
+        """A hipGraph being captured replays into this plan's arena: the graph keeps the handle (``capture_graph``: ``graph._sky_keep``),
+        so eviction, ``calibrate()`` or a weight change only drop the cache's reference and the arena lives as long as the graph."""
+        from ...utils import metrics as _metrics
+        if _metrics._KEEP:
+            _metrics._KEEP[-1].append(h)
 
     def export_engine(self, path, *example_inputs):
         """Write the engine's own weight file for the geometry of ``example_inputs`` (export.py counterpart):
         an .npz with, per packed convolution i, ``conv{i}.weight`` [rows, kpad] (float32, or uint16 = bf16 bits),
-        ``conv{i}.bias`` [rows] float32 and a JSON ``index`` (state-dict name, cout, kernel_size, cin, dtype).  BatchNorm is
-        folded (blocks.py:39-41 ``fused_forward``), K is (ky, kx, cin).  Returns the index."""
+        ``conv{i}.bias`` [rows] float32, ``conv{i}.scale`` [rows] float32 and a JSON ``index`` (state-dict name, cout, kernel_size,
+        cin, dtype).  BatchNorm is folded (blocks.py:39-41 ``fused_forward``), K is (ky, kx, cin); the stored values are what the
+        kernels read: real weight = stored * scale (fp8 row scales; ln 2 for the SiLU layers of the bf16 engine, whose weights and
+        bias are kept times log2 e -- include/skyeye_hip.h: sky_packed_scales).  Returns the index."""
         import json
         import numpy as np
         h = self._engine([self._prepare_input(t) for t in example_inputs])
         packed = h.packed_weights()
         arrays, index = {}, []
         for i, p in enumerate(packed):
-            arrays[f"conv{i}.weight"], arrays[f"conv{i}.bias"] = p["weight"], p["bias"]
+            arrays[f"conv{i}.weight"], arrays[f"conv{i}.bias"], arrays[f"conv{i}.scale"] = p["weight"], p["bias"], p["scale"]
             index.append(dict(i=i, name=p["name"], cout=p["cout"], kernel_size=p["kernel_size"], cin=p["cin"],
                               dtype="float32" if p["weight"].dtype == np.float32 else "bfloat16"))
         arrays["index"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
@@ -355,8 +372,13 @@ class NativeModule(nn.Module):
                 return False
         elif inputs[0].shape[0] % nsl or inputs[0].shape[0] < 2 * nsl:
             return False
-        if self._resolved_precision() == "fp8" and not self.__dict__.get("_calib_inputs"):
-            return False                # every slice would calibrate itself on its own frames: other scales than the whole batch
+        if self._resolved_precision() == "fp8":
+            # the predicate of _engine_entry: a slice plan takes the common calibration frames only when they have the slices' geometry and
+            # device; otherwise every slice would calibrate itself on its own frames (other scales than the whole batch, results that
+            # depend on the batch's composition) -> the whole-batch call
+            cal = self.__dict__.get("_calib_inputs")
+            if not (cal and len(cal) == len(inputs) and all(c.shape[1:] == t.shape[1:] and c.device == t.device for c, t in zip(cal, inputs))):
+                return False
         return True
 
     def _run_sliced(self, inputs, extra_cfg, skip, nsl, post=None):
@@ -372,7 +394,11 @@ class NativeModule(nn.Module):
         if streams is None or len(streams) != nsl:
             streams = st[dev.index or 0] = [torch.cuda.Stream(device=dev) for _ in range(nsl)]
         parts = [[t[lo[i]:hi[i]] for t in inputs] for i in range(nsl)]
-        ents = [self._engine_entry(parts[i], extra_cfg, slot=i + 1) for i in range(nsl)]       # (plans are made on the caller's stream)
+        self.__dict__["_pinned"] = set()
+        try:
+            ents = [self._engine_entry(parts[i], extra_cfg, slot=i + 1) for i in range(nsl)]   # (plans are made on the caller's stream)
+        finally:
+            self.__dict__["_pinned"] = None
         shapes = [(B,) + tuple(sh[1:]) for sh in ents[0][1].output_shapes()]
         cache = self._out_cache
         ckey = ("sliced", (self.__dict__.get("_out_slot", 0), sizes), ents[0][0])

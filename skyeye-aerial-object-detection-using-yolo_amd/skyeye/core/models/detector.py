@@ -179,11 +179,12 @@ class SkyEyeDetector(NativeModule):
             return outs[0], outs[1:]
         return outs[1:]
 
-    def detect_nms(self, x, conf_threshold=0.25, iou_threshold=0.45, max_detections=300, **nms_kw):
+    def detect_nms(self, x, conf_threshold=0.25, iou_threshold=0.45, max_detections=300, out=None, **nms_kw):
         """forward (raw levels not written) + non_max_suppression in one asynchronous call -> (rows [B, max_det, 7], counts [B]) on the
         device, the ``skyeye.utils.metrics.nms_raw`` result of ``self(x)[0]`` (validate.py:245-255 / detect.py:140-145 do exactly this
         pair).  An extension: with ``parallel_slices`` the NMS of a slice is enqueued on that slice's stream, so it runs beside the
-        other slice's convolutions instead of behind the join."""
+        other slice's convolutions instead of behind the join.  ``out``: (rows, counts) to write into -- e.g. the views of a
+        ``skyeye.distributed.BoxExchange`` block, so that the boxes land in the buffer the all-gather sends."""
         from ...utils.metrics import nms_raw
         if self.training:
             raise RuntimeError("detect_nms is an eval-mode call")
@@ -193,7 +194,7 @@ class SkyEyeDetector(NativeModule):
             B = xi.shape[0]
             cache = self._out_cache
             ck = ("nms", B, int(max_detections))
-            bufs = cache.get(ck) if cache is not None else None
+            bufs = out if out is not None else (cache.get(ck) if cache is not None else None)
             if bufs is None:
                 bufs = (torch.empty((B, int(max_detections), 7), dtype=torch.float32, device=xi.device),
                         torch.empty((B,), dtype=torch.int32, device=xi.device))
@@ -207,16 +208,19 @@ class SkyEyeDetector(NativeModule):
             self._run_sliced([xi], None, (1, 2, 3), nsl, post=post)
             return rows, counts
         det = self._run([xi], skip=(1, 2, 3))[0]
+        if out is not None:
+            return nms_raw(det, conf_threshold, iou_threshold, max_detections=max_detections, out=out[0], counts=out[1], **nms_kw)
         return nms_raw(det, conf_threshold, iou_threshold, max_detections=max_detections, **nms_kw)
 
-    def detect_nms_pipelined(self, x, conf_threshold=0.25, iou_threshold=0.45, max_detections=300, parity=None, **nms_kw):
+    def detect_nms_pipelined(self, x, conf_threshold=0.25, iou_threshold=0.45, max_detections=300, parity=None, out=None, **nms_kw):
         """A two-deep software pipeline over a stream of batches (an extension; validate.py:245-255 / detect.py:140-145 run the pair
         strictly one after the other): the forward pass of THIS batch is enqueued beside the non_max_suppression of the PREVIOUS one,
         which otherwise runs alone behind the join -- a chain of seven small kernels on a few CUs, 0.145 of 4.35 ms on the benchmark
         batch.  Returns (rows [B, max_det, 7], counts [B]) of the previous batch, or None for the first call; ``detect_nms_flush()``
         returns the last batch's.  Two sets of detection / NMS buffers alternate (``parity`` 0 / 1; given explicitly when the two
         forms are captured as two hipGraphs, else it toggles per call).  Needs ``reuse_output_buffers(True)``.  Same results as
-        ``detect_nms`` on every batch (tests/test_gpu_slices.py)."""
+        ``detect_nms`` on every batch (tests/test_gpu_slices.py).  ``out``: (rows, counts) for the PREVIOUS batch's boxes (the views of
+        a ``BoxExchange`` block) instead of the module's own buffers."""
         from ...utils.metrics import nms_raw
         if self.training:
             raise RuntimeError("detect_nms_pipelined is an eval-mode call")
@@ -230,11 +234,9 @@ class SkyEyeDetector(NativeModule):
         cur = torch.cuda.current_stream(dev)
         side = st["streams"].get(dev.index or 0)
         if side is None:
-            # lowest priority: the NMS kernels take the CUs the convolutions leave (7 423 / 7 402 against 7 336 / 7 356 frames/s, alternating)
-            try:
-                side = torch.cuda.Stream(device=dev, priority=1)
-            except Exception:  # noqa: BLE001 -- a runtime without a low-priority level
-                side = torch.cuda.Stream(device=dev)
+            # default priority: torch clamps a positive (lower-than-default) priority to 0, so no lower level is reachable through
+            # torch.cuda.Stream -- round 3's "low-priority NMS stream, +0.9 %" was this same stream and run-to-run noise
+            side = torch.cuda.Stream(device=dev)
             st["streams"][dev.index or 0] = side
         if parity is not None and st.get(("det", 1 - p)) is None:            # explicit parity (graph capture): the other set must exist
             self.__dict__["_out_slot"] = 2 - p
@@ -248,7 +250,7 @@ class SkyEyeDetector(NativeModule):
             result = nms_raw(prev, conf_threshold, iou_threshold, max_detections=max_detections, **nms_kw)
         elif prev is not None:
             ck = ("nms_pipe", B, int(max_detections), 1 - p)
-            bufs = self._out_cache.get(ck)
+            bufs = out if out is not None else self._out_cache.get(ck)
             if bufs is None:
                 bufs = self._out_cache[ck] = (torch.empty((B, int(max_detections), 7), dtype=torch.float32, device=dev),
                                               torch.empty((B,), dtype=torch.int32, device=dev))

@@ -56,6 +56,51 @@ def all_gather_detections(rows, counts, group=None):
     return unpack_detections(out.reshape(world * packed.shape[0], -1), rows.shape[1], rows.shape[2])
 
 
+class BoxExchange:
+    """The exchange step with every buffer allocated ONCE (per geometry): nothing is allocated, packed or unpacked per step, so the
+    step is a fixed sequence of launches on fixed addresses (capturable in a hipGraph together with the forward pass and the NMS).
+
+    Layout of a rank's block (int32 storage; a collective only moves bytes, no arithmetic ever touches the words):
+        image b:  [ max_det * cols float32 rows | int32 count ]           = max_det * cols + 1 words, images back to back
+    ``rows`` / ``counts`` are strided VIEWS of the local block: hand them to ``nms_raw(..., out=ex.rows, counts=ex.counts)`` (or to
+    ``detect_nms``) and the NMS kernel writes the block in place.  ``gather()`` sends it with one ``all_gather_into_tensor`` (RCCL)
+    into the [world * B_local] block buffer; ``all_rows`` / ``all_counts`` are views of that buffer in rank order: the result of the
+    1-process run, bit for bit.  world == 1 (or no process group): the views of the local block, no copy."""
+
+    def __init__(self, b_local, max_det=300, cols=7, device="cpu", group=None, always_collective=False):
+        """``always_collective``: run the collective at world size 1 too (readiness tests on one GPU: the RCCL call the 8-GPU run makes)."""
+        self.group = group
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.collective = self.world > 1 or (inited and always_collective)
+        self.b_local, self.max_det, self.cols = int(b_local), int(max_det), int(cols)
+        self.words = self.max_det * self.cols + 1
+        self.local = torch.zeros((self.b_local, self.words), dtype=torch.int32, device=device)
+        self.rows, self.counts = self._views(self.local)
+        if self.collective:
+            self.gathered = torch.zeros((self.world * self.b_local, self.words), dtype=torch.int32, device=device)
+            self.all_rows, self.all_counts = self._views(self.gathered)
+        else:
+            self.gathered, self.all_rows, self.all_counts = self.local, self.rows, self.counts
+
+    def _views(self, blocks):
+        n = blocks.shape[0]
+        rows = blocks.view(torch.float32).as_strided((n, self.max_det, self.cols), (self.words, self.cols, 1))
+        counts = blocks.as_strided((n,), (self.words,), self.words - 1)
+        return rows, counts
+
+    def gather(self):
+        """-> (all_rows [world * B_local, max_det, cols], all_counts [world * B_local]); asynchronous on the current stream."""
+        if self.collective:
+            if dist.get_backend(self.group) == "gloo" and not self.local.is_cuda:
+                parts = list(self.gathered.view(self.world, self.b_local, self.words).unbind(0))      # views: gloo writes in place
+                dist.all_gather(parts, self.local, group=self.group)
+            else:
+                # RCCL: ONE fused collective; an error here is an RCCL / xGMI failure and must surface
+                dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        return self.all_rows, self.all_counts
+
+
 def detections_to_list(rows, counts, cols):
     """Device buffers -> the reference's list-of-tensors format (metrics.py:457)."""
     host = counts.cpu().tolist()

@@ -47,7 +47,8 @@ def forget_stream(device_index, stream):
 def nms_raw(prediction, conf_threshold=0.25, iou_threshold=0.45, classes=None, agnostic=False, multi_label=False,
             max_detections=300, mode="literal", max_nms=30000, max_wh=4096.0, out=None, counts=None):
     """Asynchronous form: returns (rows [B, max_det, 7] float32, counts [B] int32) on the device, no host sync.  ``out`` / ``counts``:
-    contiguous tensors (or batch slices of them) to write into instead of fresh ones."""
+    tensors (or batch slices of them) to write into instead of fresh ones; the image dimension may be strided (the views of a
+    ``skyeye.distributed.BoxExchange`` block: the kernel writes straight into the buffer the all-gather sends)."""
     if not prediction.is_cuda:
         raise N.SkyEyeNativeError("non_max_suppression: prediction must be on the HIP device (no CPU path)")
     pred = prediction.float().contiguous()
@@ -67,9 +68,13 @@ def nms_raw(prediction, conf_threshold=0.25, iou_threshold=0.45, classes=None, a
         out = torch.empty((B, max_detections, 7), dtype=torch.float32, device=pred.device)
     if counts is None:
         counts = torch.empty((B,), dtype=torch.int32, device=pred.device)
-    if tuple(out.shape) != (B, max_detections, 7) or out.dtype != torch.float32 or not out.is_contiguous() or \
-            tuple(counts.shape) != (B,) or counts.dtype != torch.int32 or not counts.is_contiguous():
-        raise N.SkyEyeNativeError("nms_raw: out must be a contiguous float32 [B, max_detections, 7] and counts a contiguous int32 [B]")
+    if tuple(out.shape) != (B, max_detections, 7) or out.dtype != torch.float32 or out.stride()[1:] != (7, 1) or \
+            (B > 1 and out.stride(0) < max_detections * 7) or tuple(counts.shape) != (B,) or counts.dtype != torch.int32 or \
+            (B > 1 and counts.stride(0) < 1):
+        raise N.SkyEyeNativeError("nms_raw: out must be float32 [B, max_detections, 7] with dense rows and counts int32 [B] "
+                                  "(only the image dimension may be strided)")
+    p.out_image_stride = int(out.stride(0)) if B > 1 else 0
+    p.counts_stride = int(counts.stride(0)) if B > 1 else 0
     stream = torch.cuda.current_stream(pred.device).cuda_stream
     h = _handle(pred.device.index or 0, stream)
     N.check(h.L.sky_nms(h.h, pred.data_ptr(), B, Nrows, no - 5, ctypes.byref(p), out.data_ptr(), counts.data_ptr(),

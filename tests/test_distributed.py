@@ -1,4 +1,5 @@
-"""N > 1 data path on CPU: world_size-2 gloo processes exercise sharding and the fused box all-gather."""
+"""N > 1 data path on CPU: gloo process groups of 2 and 8 ranks exercise sharding, the fused box all-gather (the legacy packed form and
+BoxExchange, whose buffers are allocated once and which the NMS kernel writes in place) and the tile-survivor gather of tiled inference."""
 import os
 import socket
 
@@ -8,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from skyeye.distributed import all_gather_detections, pack_detections, shard_bounds, unpack_detections
+from skyeye.distributed import BoxExchange, all_gather_detections, pack_detections, shard_bounds, unpack_detections
 
 
 def _free_port():
@@ -137,3 +138,84 @@ def test_tile_survivor_gather_world2_gloo_keeps_tile_order():
         assert np.array_equal(counts[real], counts1.numpy())
         empty = sorted(set(range(world * per)) - set(real))
         assert not counts[empty].any() and not rows[empty].any()
+
+
+# ---- world size 8: the geometry of BASELINE.json configs[3] (B = 256 -> 32 frames per rank) through BoxExchange ----------------
+def _exchange_worker(rank, world, port, n_items, max_det, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(n_items, rank, world)
+    rows_all, counts_all = _fake_result(7, n_items, max_det)          # what ONE process would hold for the whole batch
+    ex = BoxExchange(hi - lo, max_det, 7)
+    ptr = ex.local.data_ptr()
+    for step in range(2):                                              # two steps through the SAME buffers (nothing is allocated per step)
+        ex.rows.copy_(rows_all[lo:hi] + step)                          # the NMS kernel writes these views in place on the GPU
+        ex.counts.copy_(counts_all[lo:hi])
+        all_rows, all_counts = ex.gather()
+        assert ex.local.data_ptr() == ptr and all_rows.data_ptr() == ex.gathered.data_ptr()
+    q.put((rank, all_rows.clone().numpy(), all_counts.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_box_exchange_world8_gloo_b256_equals_one_process():
+    world, n_items, max_det = 8, 256, 20
+    assert [shard_bounds(n_items, r, world) for r in (0, 7)] == [(0, 32), (224, 256)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_items, max_det, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows1, counts1 = _fake_result(7, n_items, max_det)
+    rows1 = (rows1 + 1).numpy()
+    for rank, rows, counts in got:
+        assert rows.shape == (n_items, max_det, 7)
+        assert np.array_equal(rows.view(np.uint32), rows1.view(np.uint32)) and np.array_equal(counts, counts1.numpy())
+
+
+def test_box_exchange_single_process_views():
+    """No process group: the gathered views ARE the local block; rows / counts are strided views of ONE int32 buffer."""
+    ex = BoxExchange(3, 4, 7)
+    ex.rows.copy_(torch.arange(3 * 4 * 7, dtype=torch.float32).reshape(3, 4, 7))
+    ex.counts.copy_(torch.tensor([1, 0, 4], dtype=torch.int32))
+    assert ex.rows.stride() == (4 * 7 + 1, 7, 1) and ex.counts.stride() == (4 * 7 + 1,)
+    assert ex.local[1, :4].view(torch.float32).tolist() == [28.0, 29.0, 30.0, 31.0] and ex.local[:, -1].tolist() == [1, 0, 4]
+    r, c = ex.gather()
+    assert r.data_ptr() == ex.rows.data_ptr() and torch.equal(c, ex.counts)
+
+
+@pytest.mark.timeout(300)
+def test_tile_survivor_gather_world8_12_tiles_uneven_shards():
+    """12 tiles (a 3000 x 4000 frame) over 8 ranks: four ranks hold two tiles, four hold one and an empty block; dropping the empty
+    blocks of the gathered buffer gives the 1-process tile sequence bit for bit."""
+    from skyeye.utils.tta import tile_shard
+    world, n_tiles, R = 8, 12, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n_tiles, R, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows1, counts1 = _fake_survivors(n_tiles, R)
+    per = tile_shard(n_tiles, 0, world)[2]
+    sizes = [tile_shard(n_tiles, r, world)[1] - tile_shard(n_tiles, r, world)[0] for r in range(world)]
+    assert per == 2 and sorted(sizes) == [1, 1, 1, 1, 2, 2, 2, 2]
+    real = []
+    for r in range(world):
+        lo, hi, _ = tile_shard(n_tiles, r, world)
+        real += [r * per + k for k in range(hi - lo)]
+    for rank, rows, counts in got:
+        assert rows.shape == (world * per, R, 7)
+        assert np.array_equal(rows[real].view(np.uint32), rows1.numpy().view(np.uint32)) and np.array_equal(counts[real], counts1.numpy())
+        empty = sorted(set(range(world * per)) - set(real))
+        assert len(empty) == 4 and not counts[empty].any() and not rows[empty].any()

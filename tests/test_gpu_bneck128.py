@@ -1,5 +1,6 @@
-"""BottleneckBlock(128, 128) as ONE kernel (k_bneck.hip: cv1 on the halo tile, u kept in LDS, weights through a four-stage ring with
-counted waits): bit-identical to the two-launch form (SKY_NO_BNECK128=1: 1x1 on the streaming kernel + 3x3 with residual on the
+"""BottleneckBlock(128, 128) as ONE kernel -- round 4's two 4-wave workgroups per CU on 8 x 16 tiles (k_bneck_w.hip, the default) and round 3's
+one 8-wave workgroup per CU on 16 x 16 tiles (k_bneck.hip: SKY_BNECK128=solo; cv1 on the halo tile, u kept in LDS, weights through a four-stage
+ring with counted waits): both bit-identical to the two-launch form (SKY_NO_BNECK128=1: 1x1 on the streaming kernel + 3x3 with residual on the
 halo-tile kernel) -- same MFMA instructions in the same K order, same bf16 roundings -- on CSP blocks with 2, 3 and 4 bottlenecks,
 ragged maps (image borders inside tiles), the 80 x 80 size of the detector at B = 32 (several tiles per workgroup, the ring running
 across tile boundaries) and the single-tile / last-tile cases; deterministic; close to the fp32 engine."""
@@ -17,10 +18,12 @@ pytestmark = pytest.mark.gpu
 CASES = [(3, 2, 48, 48), (2, 1, 16, 16), (2, 2, 40, 56), (4, 1, 33, 47), (3, 32, 80, 80), (3, 2, 24, 100), (2, 3, 160, 160)]
 
 
-def _run(n, x, fused, shortcut=True):
+def _run(n, x, fused, shortcut=True, solo=False):
     m = load_seeded(M.CSPBlock(256, 256, num_blocks=n, shortcut=shortcut), 23).set_precision("bf16")
     if not fused:
         os.environ["SKY_NO_BNECK128"] = "1"
+    if solo:
+        os.environ["SKY_BNECK128"] = "solo"
     os.environ["SKY_CONV_HALO"] = "force"         # ragged maps: both forms take the halo-tile kernels whatever the tile fill
     try:
         y = m(x)
@@ -28,6 +31,7 @@ def _run(n, x, fused, shortcut=True):
         info = [h.op_info(i) for i in range(h.stats()["launches"])]
     finally:
         os.environ.pop("SKY_NO_BNECK128", None)
+        os.environ.pop("SKY_BNECK128", None)
         os.environ.pop("SKY_CONV_HALO", None)
     return y, info
 
@@ -44,6 +48,10 @@ def test_bneck128_equals_two_launch_form(case):
     assert torch.equal(yf, yu), f"{int((yf != yu).sum())} of {yf.numel()} values differ, max {float((yf - yu).abs().max())}"
     yf2, _ = _run(n, x, True)
     assert torch.equal(yf, yf2)
+    assert sum("bneck128x2" in t for t in info_f) == n, info_f             # the default is the two-workgroups-per-CU kernel ...
+    ys, info_s = _run(n, x, True, solo=True)                                # ... and round 3's kernel gives the same bits
+    assert sum("bneck128" in t for t in info_s) == n and not any("bneck128x2" in t for t in info_s), info_s
+    assert torch.equal(ys, yu)
 
 
 def test_bneck128_without_shortcut():

@@ -39,6 +39,14 @@ def test_export_folds_batchnorm_and_orders_k(tmp_path, prec):
     want_w = (P["conv.weight"] * scale[:, None, None, None]).transpose(0, 2, 3, 1).reshape(48, -1)       # [cout][(ky, kx, cin)]
     K = want_w.shape[1]
     assert w.shape[0] >= 48 and w.shape[1] >= K
+    sc = z["conv0.scale"]
+    if prec == "bf16":
+        # a SiLU layer of the bf16 engine lives in the exp2 domain: weights and bias are stored times log2 e, scale = ln 2
+        np.testing.assert_allclose(sc[:48], np.log(2.0), rtol=1e-6)
+        want_b = (want_b.astype(np.float64) * np.log2(np.e)).astype(np.float32)
+        want_w = (want_w.astype(np.float64) * np.log2(np.e)).astype(np.float32)
+    else:
+        assert (sc == 1.0).all()
     np.testing.assert_allclose(b[:48], want_b, rtol=1e-6, atol=1e-7)
     if prec == "fp32":
         np.testing.assert_allclose(w[:48, :K], want_w, rtol=1e-6, atol=1e-8)

@@ -19,7 +19,7 @@ def family(k):
         return "stem_down"
     if "csp_stage_kernel" in k:
         return "csp_stage"
-    if "bneck128_kernel" in k:
+    if "bneck128" in k:
         return "bneck128"
     if "conv3x3_deep_kernel" in k:
         return "deep3x3"
