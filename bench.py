@@ -150,8 +150,21 @@ def _native_build():
     return {"library_sources": _native.build_info(), "matches_tree": None if src is None else src == _native.build_info()}
 
 
-OTHER_CONFIGS = [   # BASELINE.json configs[2], [3] (one GPU's shard), [4] (one GPU's shard): short legs behind the headline measurement
-    ("skyeye_s_ha", "bf16", 1280), ("skyeye_l", "bf16", 1280), ("skyeye_l", "fp8", 1536)]
+OTHER_CONFIGS = [   # BASELINE.json configs[2], [3] (one GPU's shard), [4] (one GPU's shard): short legs behind the headline measurement;
+    # last: the headline workload on the fp32 (exact) engine -- the engine the 1e-4 parity tests pin -- so that it has a driver-visible number
+    ("skyeye_s_ha", "bf16", 1280), ("skyeye_l", "bf16", 1280), ("skyeye_l", "fp8", 1536), ("skyeye_s", "fp32", 1280)]
+
+
+def plan_gflop_per_frame(model, x):
+    """Algorithmic GFLOP per frame of the planned graph (sky_plan_stats: 2 * MAC over every convolution / linear layer AND the
+    attention products of the head-attention variant), from the plan the leg really ran (a slice plan when the batch is sliced)."""
+    nsl = model.__dict__.get("_slices", 1)
+    xi = model._prepare_input(x)
+    if nsl > 1 and model._sliceable([xi], nsl):
+        sizes = model.__dict__.get("_slice_sizes") or (xi.shape[0] // nsl,) * nsl
+        part = xi[:sizes[0]]
+        return model._engine_entry([part], None, slot=1)[1].stats()["flops"] / part.shape[0] / 1e9
+    return model._engine([xi]).stats()["flops"] / xi.shape[0] / 1e9
 
 
 def main():
@@ -172,16 +185,37 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     ranks_seen = 1
-    if world > 1:
+    # readiness switch (one GPU): run the N > 1 code path -- exchange blocks written by the NMS kernel, the RCCL all-gather of every step, the
+    # per-rank reductions -- on a world-size-1 nccl group, so that the first multi-GPU run is not the first time this code executes
+    force_ex = world == 1 and bool(os.environ.get("SKY_BENCH_FORCE_EXCHANGE"))
+    if world > 1 or force_ex:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one)
-        ranks_seen = int(one.item())
+        # RCCL prints a version banner on STDOUT when the first communicator is made: the contract is ONE JSON line there, so the
+        # C-level stdout goes to stderr until the first collective has run
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        if force_ex:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        try:
+            one = torch.ones(1, device=dev)
+            dist.all_reduce(one)
+            ranks_seen = int(one.item())
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
+    multi = world > 1 or force_ex
 
     from skyeye.utils.metrics import nms_raw
     from skyeye.utils.torch_utils import capture_graph
-    from skyeye.distributed import all_gather_detections
+    from skyeye.distributed import BoxExchange
 
     def timed_leg(model_name, precision, size, steps, warmup):
         """Build + calibrate a detector, capture forward + NMS (+ the RCCL all-gather when world > 1) and time `steps` steps between
@@ -195,16 +229,34 @@ def main():
         calibrate_objectness(model, x, 0.01, a.conf)
         model.reuse_output_buffers(True)
 
-        if a.slices and precision != "fp8":
+        if a.slices:
             model.parallel_slices([int(v) for v in a.slices.split(",")])
-        elif a.streams > 1 and precision != "fp8":
-            model.parallel_slices(a.streams)                     # the batch as equal slices on parallel HIP streams, one plan each
+        elif a.streams > 1:
+            # the batch as equal slices on parallel HIP streams, one plan each (fp8: the slices share the calibration frames given above)
+            model.parallel_slices(a.streams)
+
+        # N > 1: the NMS kernel writes its rows / counts straight into the block the all-gather sends (skyeye.distributed.BoxExchange:
+        # buffers allocated once per leg, no packing kernels, no allocation per step); three blocks = strict order + the two parities
+        # of the pipelined loop.  N == 1: the module's own buffers.
+        ex = [BoxExchange(B, 300, 7, dev, always_collective=force_ex) for _ in range(3)] if multi else None
+        ag = {"ms": 0.0, "n": 0, "ev": []}
+
+        def gather(e):
+            """the RCCL all-gather of one block, bracketed by events on the stream it is enqueued on (allgather_ms of the line)"""
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res = e.gather()
+            e1.record()
+            ag["ev"].append((e0, e1))
+            return res
 
         def local_step():
+            out = (ex[2].rows, ex[2].counts) if ex else None
             if a.with_raw or a.streams <= 1:
                 det, _raw = model(x, return_raw=a.with_raw)                         # detector.py:300-324
-                return nms_raw(det, a.conf, a.iou, max_detections=300)              # metrics.py:361-457, no host sync
-            return model.detect_nms(x, a.conf, a.iou, max_detections=300)           # the same pair; each slice's NMS on its own stream
+                return nms_raw(det, a.conf, a.iou, max_detections=300,              # metrics.py:361-457, no host sync
+                               **(dict(out=out[0], counts=out[1]) if out else {}))
+            return model.detect_nms(x, a.conf, a.iou, max_detections=300, out=out)  # the same pair; each slice's NMS on its own stream
 
         graph = None
         if not a.no_graph:
@@ -216,8 +268,8 @@ def main():
                 rows, counts = held
             else:
                 rows, counts = local_step()
-            if world > 1:
-                rows, counts = all_gather_detections(rows, counts)                  # RCCL over xGMI
+            if multi:
+                rows, counts = gather(ex[2])                                        # RCCL over xGMI
             return rows, counts
 
         pipelined = not a.no_pipeline and not a.with_raw
@@ -225,12 +277,14 @@ def main():
             # throughput form: step k = forward(batch k) beside NMS(batch k - 1) (two buffer sets, two graphs replayed alternately);
             # finish() = the last batch's NMS, inside the timed region: K steps do K forward passes and K + 1 NMS calls
             def pipe_step(p):
-                return model.detect_nms_pipelined(x, a.conf, a.iou, max_detections=300, parity=p)
+                # the boxes of the PREVIOUS batch (parity 1 - p) land in exchange block 1 - p
+                return model.detect_nms_pipelined(x, a.conf, a.iou, max_detections=300, parity=p,
+                                                  out=(ex[1 - p].rows, ex[1 - p].counts) if ex else None)
             graphs = None if a.no_graph else [capture_graph(lambda p=p: pipe_step(p), warmup=2) for p in (0, 1)]
             # two steps (parity 0 then 1) as ONE replay where nothing happens between them on the host: one graph-launch gap per two batches
             pair = None
             npair = max(1, int(os.environ.get("SKY_BENCH_PAIRS", "2")))          # even / odd pairs per replay
-            if graphs is not None and world == 1 and not os.environ.get("SKY_BENCH_NO_PAIR"):
+            if graphs is not None and not multi and not os.environ.get("SKY_BENCH_NO_PAIR"):
                 pair = capture_graph(lambda: tuple(pipe_step(i & 1) for i in range(2 * npair)), warmup=1)
             state = {"k": 0}
 
@@ -242,8 +296,8 @@ def main():
                     res = graphs[p][1]
                 else:
                     res = pipe_step(p)
-                if world > 1 and res is not None:
-                    res = all_gather_detections(*res)
+                if multi and res is not None:
+                    res = gather(ex[1 - p])
                 return res
 
             def run_steps(n):
@@ -262,8 +316,9 @@ def main():
 
             def finish():
                 res = model.detect_nms_flush(parity=(state["k"] - 1) & 1)
-                if world > 1:
-                    res = all_gather_detections(*res)
+                if multi:
+                    ex[2].rows.copy_(res[0]); ex[2].counts.copy_(res[1])            # (the flush outside the loop: once per leg)
+                    res = gather(ex[2])
                 return res
         else:
             step = sync_step
@@ -280,6 +335,7 @@ def main():
                 return res
 
         run_steps(warmup)
+        ag["ev"].clear()
         fence()
         t0 = time.perf_counter()
         res = run_steps(steps)
@@ -287,15 +343,42 @@ def main():
         rows, counts = last if last is not None else res
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        dt_rank = dt
+        ag_ms = sum(e0.elapsed_time(e1) for e0, e1 in ag["ev"]) / max(len(ag["ev"]), 1) if ag["ev"] else None
+        ag["ev"].clear()
+        rank_fps = None
+        if multi:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            every = torch.zeros(world, device=dev, dtype=torch.float64)
+            every[rank] = B * steps / dt_rank
+            dist.all_reduce(every)
+            rank_fps = [round(float(v), 1) for v in every.tolist()]
+        # the strict order (a batch's NMS behind its own forward pass, one replay per batch): the like-for-like successor of the
+        # figure rounds 1 - 2 reported, same number of steps, same fences
+        strict = None
+        if pipelined:
+            for _ in range(2):
+                sync_step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                sync_step()
+            fence()
+            sdt = time.perf_counter() - t1
+            if multi:
+                t = torch.tensor([sdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sdt = float(t.item())
+            strict = {"frames_per_s": round(world * B * steps / sdt, 2), "ms_per_step": round(sdt / steps * 1e3, 3), "steps": steps,
+                      "what": "forward then its own NMS" + (" then the all-gather" if world > 1 else "") + ", one graph replay per batch (--no-pipeline)"}
+            ag["ev"].clear()
         return dict(model=model, P=P, x=x, frames_np=frames_np, step=sync_step, graph=graph, dt=dt, counts=counts, pipelined=pipelined,
-                    steps_per_replay=2 * npair if (pipelined and pair is not None) else 1)
+                    steps_per_replay=2 * npair if (pipelined and pair is not None) else 1, strict=strict, allgather_ms=ag_ms, rank_fps=rank_fps)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -343,6 +426,7 @@ def main():
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "p50_latency_ms": round(lat[len(lat) // 2], 3), "p99_latency_ms": round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 3),
         "rccl_ranks_seen": ranks_seen, "build": _native_build(),
+        "strict_order": leg.get("strict"),
         "buckets_ms_per_image": {"pre_process": 0.0, "inference": round(inf_ms / B, 4), "nms": round(nms_ms / B, 4),
                                  "note": "validate.py:323-326 buckets; pre-process (uint8 -> float, /255) is fused into the stem's loader"},
         "nms_worst_case": {"conf": 0.001, "ms_per_batch": round(worst_ms, 3), "ms_per_image": round(worst_ms / B, 4),
@@ -354,8 +438,14 @@ def main():
                    "mean_boxes_kept_per_image": round(kept_mean, 1), "parallelism": f"dp{world} (independent images)",
                    "hip_graph": graph is not None, "raw_levels_written": bool(a.with_raw),
                    "nms_one_batch_behind_forward": bool(leg.get("pipelined")), "steps_per_graph_replay": leg.get("steps_per_replay", 1),
-                   "batch_slices_on_parallel_streams": a.streams if a.precision != "fp8" else 1},
+                   "batch_slices_on_parallel_streams": a.streams},
     }
+    if multi:
+        rf = leg.get("rank_fps") or []
+        out["multi_gpu"] = {"allgather_ms_per_step": None if leg.get("allgather_ms") is None else round(leg["allgather_ms"], 4),
+                            "allgather_what": "hipEvent interval around the one fused all_gather_into_tensor of a step, mean over the timed steps, rank 0; "
+                                              "the NMS kernel writes the exchanged block in place (no packing), buffers allocated once",
+                            "per_rank_frames_per_s": rf, "per_rank_min": min(rf) if rf else None, "per_rank_max": max(rf) if rf else None}
 
     if rank == 0 and not a.no_roofline:
         from skyeye import _native as N
@@ -391,6 +481,9 @@ def main():
                     pmc, pmc_src, pmc_lib = pj["by_variant"], os.path.relpath(f, ROOT), pj.get("library_sources")
                 except Exception:  # noqa: BLE001
                     pass
+        pmc_fresh = bool(pmc_src) and pmc_lib == N.build_info()
+        if not pmc_fresh:
+            pmc = {}
         table = {}
         for name, e in fam.items():
             t = e["ms"] * 1e-3
@@ -401,6 +494,11 @@ def main():
                            "frac_hbm": round(e["bytes"] / t / 1e9 / PEAK_HBM_GBPS, 4) if t else 0.0,
                            "algorithmic_bytes_per_launch": round(e["bytes"] / e["launches"]),
                            "pmc_bytes_per_launch": round(sum(pb) / len(pb)) if pb else None}
+            if table[name]["frac_hbm"] > 0.79:
+                # more algorithmic bytes per second than HBM delivers (6.29 TB/s measured = 0.79 of spec): the working set of these
+                # launches (CBAM / SPP re-read a map the previous launch just wrote) is served by the 256 MB Infinity Cache
+                table[name]["served_from_cache"] = True
+                table[name]["frac_hbm_note"] = "algorithmic bytes / time; not an HBM rate: the maps are re-read from the Infinity Cache"
         desc = {n: k for n, k, _ in FAMILIES}
         conv_names = [n for n in table if n not in ("non_conv",)]
         dom = max(conv_names, key=lambda n: table[n]["ms"])
@@ -411,10 +509,12 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "achieved": round(e2e_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(e2e_tflops / peak, 4),
             "definition": "end-to-end: frames/s per GPU x algorithmic GFLOP/frame (2*MAC over conv/linear) / dense MFMA peak",
-            "traffic": round(sum(v["pmc_bytes_per_launch"] * v["launches"] for v in table.values() if v["pmc_bytes_per_launch"])) or None,
+            "traffic": (round(sum(v["pmc_bytes_per_launch"] * v["launches"] for v in table.values() if v["pmc_bytes_per_launch"])) or None) if pmc_fresh else None,
             "traffic_source": pmc_src, "traffic_note": "PMC bytes per step summed over the convolution families (FETCH_SIZE x2 + WRITE_SIZE)",
-            # the PMC pass is a separate, committed run: stale as soon as a kernel changes -- say so instead of quoting it silently
-            "traffic_measured_on_this_build": (pmc_lib == N.build_info()) if pmc_src else None,
+            # the PMC pass is a separate, committed run: stale as soon as a kernel changes -- then it is an ERROR of this line, not a number
+            "traffic_measured_on_this_build": pmc_fresh if pmc_src else None,
+            "traffic_error": None if (pmc_fresh or not pmc_src) else (f"{pmc_src} was measured on library sources {pmc_lib}, the loaded library is "
+                                                                       f"{N.build_info()}: traffic and pmc_bytes_per_launch withheld (re-run tools/pmc_traffic.sh)"),
             "graph_gflop_per_frame": round(graph_flops / B / 1e9, 2), "baseline_gflop_per_frame": GFLOP_PER_FRAME.get((a.model, S)),
             "algorithmic_bytes_per_step": round(graph_bytes), "end_to_end_hbm_gbps": round(fps / world / B * graph_bytes / 1e9, 1),
             "end_to_end_frac_hbm": round(fps / world / B * graph_bytes / 1e9 / PEAK_HBM_GBPS, 4),
@@ -480,12 +580,19 @@ def main():
             try:
                 lg = timed_leg(name, prec, size, 5, 2)
                 f = world * B * 5 / lg["dt"]
-                base = name[:-3] if name.endswith("_ha") else name
-                gf = GFLOP_PER_FRAME.get((base, size))
-                others.append({"workload": f"{name} {prec} batch={B}/GPU @{size}x{size}, forward + NMS" + (" + RCCL all-gather" if world > 1 else ""),
-                               "dtype": prec, "frames_per_s": round(f, 1), "ms_per_step": round(lg["dt"] / 5 * 1e3, 3), "steps": 5,
-                               "roofline_frac": round(f / world * gf * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4) if gf else None,
-                               "roofline_note": None if gf else "graph GFLOP per frame not in BASELINE.md for this variant"})
+                gf = plan_gflop_per_frame(lg["model"], lg["x"])                    # the plan's own count: includes the attention FLOPs of skyeye_s_ha
+                entry = {"workload": f"{name} {prec} batch={B}/GPU @{size}x{size}, forward + NMS" + (" + RCCL all-gather" if world > 1 else ""),
+                         "dtype": prec, "frames_per_s": round(f, 1), "ms_per_step": round(lg["dt"] / 5 * 1e3, 3), "steps": 5,
+                         "graph_gflop_per_frame": round(gf, 2), "peak_tflops": PEAK_TFLOPS[prec],
+                         "roofline_frac": round(f / world * gf * 1e9 / (PEAK_TFLOPS[prec] * 1e12), 4),
+                         "strict_order_frames_per_s": (lg.get("strict") or {}).get("frames_per_s"),
+                         "batch_slices_on_parallel_streams": a.streams}
+                if prec == "fp32":
+                    entry["what"] = "fp32_engine: the exact-mode engine (v_mfma_f32_16x16x4_f32; the one the 1e-4 parity tests pin) on the headline workload"
+                if multi:
+                    entry["allgather_ms_per_step"] = None if lg.get("allgather_ms") is None else round(lg["allgather_ms"], 4)
+                    entry["per_rank_frames_per_s"] = lg.get("rank_fps")
+                others.append(entry)
                 del lg
                 torch.cuda.empty_cache()
             except Exception as ex:  # noqa: BLE001 -- a failing side leg must not lose the headline line
@@ -498,7 +605,7 @@ def main():
                                                 "the skyeye_l leg the metric names at 8 GPUs is other_configs[0]")
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -281,6 +281,18 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // Exact mode (fp32, 64-channel tiles): TWO-LEVEL summation.  One accumulator chain over K = 9 taps x Cin is a chain of K / 4 fp32
+    // MFMA steps whose rounding error grows like sqrt(K): against float64 a 3x3 256 -> 256 layer measured 5.4e-7 relative rms, 3.3 x
+    // the reference's oneDNN convolution (1.65e-7; tools/fp32_layer_error.py).  Every three taps (24 MFMA steps)
+    // the partial sum moves into a second set of accumulators, so no chain is longer than max(24, 3 x chunks) additions.
+    constexpr bool TWO_LEVEL = std::is_same<T, float>::value && NF == 4;
+    f32x4_t tot[TWO_LEVEL ? NF : 1][4];
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tot[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- fused cv1 (CV1) ----
     typename Out8<TO>::raw_t resv[4][NF / 2];          // residual x of this lane's output vectors, taken from the LDS tile
@@ -521,8 +533,22 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             if (g > 0 && g + 1 < G && !(SKY_DBG(a) & 4)) issue_w(tap_step<S2>(nq).tap, nchk, (g + 1) & 1);
             if (!(SKY_DBG(a) & 1)) compute_tap(st.tap, g & 1);
             dbg_stamp(a, stamps, nth, 2 + 2 * g);
+            if constexpr (TWO_LEVEL) {
+                if (q % 3 == 2) {                       // (uniform) partial sum of three taps -> second level; nine taps per chunk: every chunk ends flushed
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { tot[j][i] += acc[j][i]; acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+                }
+            }
             q = nq;
             chunk = nchk;
+        }
+        if constexpr (TWO_LEVEL) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[j][i] = tot[j][i]; tot[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
         }
         // the next tile's first halo tile and weight slab are requested BEFORE this tile's epilogue: their latency runs
         // under the activation math and the stores
@@ -1253,7 +1279,8 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     }
     // 128-channel tiles where Cout allows (two workgroups per CU).  A/B switches: SKY_HALO_NF8=off -> 64-channel tiles everywhere,
     // SKY_HALO_NF8=solo -> 128-channel tiles alone on a CU (3x3 128->128 @80x80: 74.5 us default, 82 us off, 96 us solo)
-    const int nb = (a.Cout % 128 == 0 && !(a.opts & OPT_NF8_OFF)) ? 128 : 64;
+    // fp32 (exact mode): 64-channel tiles, whose second accumulator set (two-level summation, conv_halo_kernel) fits the register file
+    const int nb = (a.Cout % 128 == 0 && !(a.opts & OPT_NF8_OFF) && dtype != 0) ? 128 : 64;
     const bool sq = a.tile_w == 16 && a.tile_h == 16;
     hipError_t e;
 #define SKY_HALO(T, S2V) (nb == 128 ? (sq ? halo_launch<T, 8, true, S2V>(a, s, n_cu) : halo_launch<T, 8, false, S2V>(a, s, n_cu)) \

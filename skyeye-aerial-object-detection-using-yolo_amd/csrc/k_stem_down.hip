@@ -41,8 +41,15 @@ constexpr int S2D_BYTES = 2 * S2D_PLANE;
 constexpr int NPIX = (S2D_SLOTS + NT - 1) / NT;           // space-to-depth pixels per thread (3)
 // parity planes of the stem tile: cells per (parity, K-group) plane, padded to a multiple of 16 cells (256 B)
 constexpr int PC00 = 304, PC01 = 272, PC10 = 272, PC11 = 256;      // 17x17 (pitch 17), 17x16 (16), 16x17 (17), 16x16 (16)
-constexpr int PB00 = 0, PB01 = PB00 + 4 * PC00 * 16, PB10 = PB01 + 4 * PC01 * 16, PB11 = PB10 + 4 * PC10 * 16;
-constexpr int STEM_BYTES = PB11 + 4 * PC11 * 16;          // 70 656
+// The two column parities of a stem row are written by ALTERNATE lanes of one ds_write_b128 (phase B: lane fr -> stem pixel sx0 + fr, cell
+// sx >> 1 of plane sx & 1): the store unit takes 8 consecutive lanes per LDS cycle = 4 cells of either plane, 64 bytes each.  With both
+// planes at the same offset modulo 128 bytes those two runs fall on the SAME 16 banks (round 2 / 3: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+// = 0.205 for this kernel); the odd-column planes therefore start 64 bytes further, so that the eight lanes cover 32 distinct banks.
+// (Every read of a plane is 16 consecutive cells of ONE plane: its banking does not depend on the plane's base.)
+constexpr int PB00 = 0, PB01 = PB00 + 4 * PC00 * 16 + 64, PB10 = PB01 + 4 * PC01 * 16 + 64, PB11 = PB10 + 4 * PC10 * 16 + 64;
+constexpr int STEM_BYTES = PB11 + 4 * PC11 * 16 + 64;     // 70 912
+static_assert(PB00 % 128 == 0 && PB10 % 128 == 0 && PB01 % 128 == 64 && PB11 % 128 == 64, "odd-column planes 64 bytes off the even ones");
+static_assert(STEM_BYTES % 256 == 0, "the space-to-depth tile behind the stem tile stays 256-byte aligned");
 constexpr int KS1 = 5;                                    // 64-byte K-steps of the stem GEMM (288 bytes of K)
 constexpr int W1_BYTES = KS1 * C1 * 64;                   // 10 240
 constexpr int W2_BYTES = 9 * C2 * 64;                     // 36 864

@@ -58,20 +58,30 @@ def run(case, precision, as_uint8=False):
 
 
 def tol_for(case):
-    # the cross-layer attention of the Enhanced detector (column softmax over image rows, x4) amplifies fp32
-    # summation-order differences ~2.5x more than the plain graph; the oracle itself sits at 2.5e-4 from torch there.
-    # Measured margins (gpurun_out/parity_margins.json, r02_a): plain graphs worst |d| / limit 0.15 - 0.47 at 1e-4, the
-    # head-attention graphs 0.35 at 1e-4 (they ran at 3e-4 in round 1), enh_s_128x96 1.35 at 1e-4 -> stays at 3e-4.
-    # Round 3: with the attention core itself computed in double (scores, exp terms, softmax denominator) the margin is 1.37 -- the
-    # difference to the fixture is made by the fp32 convolutions around the column softmax (summation order of K = 256 .. 512
-    # products), which the softmax turns into relative errors of whole columns; it is not this side's softmax arithmetic.
-    return 3e-4 if case.get("enhanced") else 1e-4
+    # Column tolerance (tests/parity.det_close) -- 1e-4, the north star's, for every graph but the Enhanced detector's.  Error budget of
+    # round 4 (profiles/r04_f64_error_budget.json, tests/test_f64_error_budget.py: the graph evaluated in float64 on the CPU):
+    #     enh_s_128x96, worst |d| / (1e-4 x scale):  reference fixture vs f64 0.587   fp32 engine vs f64 1.125   engine vs fixture 1.242
+    # The reference's OWN fp32 result (oneDNN) is 0.59e-4 from the true value of its graph and the engine 1.13e-4 (the cross-layer
+    # attention's column softmax over image rows, x4, turns the fp32 rounding of the K = 256 .. 512 projections into relative errors
+    # of whole columns); two such implementations can differ by the sum, 1.71e-4.  Limit: 2e-4 (3e-4 in rounds 1 - 3).
+    return 2e-4 if case.get("enhanced") else 1e-4
 
 
 def iou_tol_for(case):
-    # IoU >= 1 - 1e-4 on matched boxes.  Every case measures 1 - min IoU <= 8.9e-5 except the two
-    # below, whose limit is twice their measured value (r02_a: l_640 1.56e-4, enh_s_128x96 3.03e-4; r02_g: l_1280 1.04e-4)
-    return {"l_640": 3.2e-4, "enh_s_128x96": 6.1e-4, "l_1280": 2.1e-4}.get(case["name"], 1e-4)
+    # IoU >= 1 - 1e-4 on matched boxes -- now for EVERY plain graph.  Rounds 1 - 3 relaxed l_640 (1.56e-4 measured),
+    # l_1280 (1.04e-4) and enh_s_128x96 (3.03e-4) to twice their measured values without knowing whose rounding it was.  The float64
+    # budget (1 - min IoU against the f64 evaluation of the same graph):
+    #     case            reference fixture   fp32 engine r03   fp32 engine r04 (two-level summation in the 3x3 kernels)
+    #     l_640           0.76e-4             1.04e-4           0.79e-4   -> engine vs fixture 1.56e-4 -> 0.96e-4
+    #     l_1280          0.75e-4             0.93e-4           0.81e-4   -> engine vs fixture 1.04e-4 -> 0.92e-4
+    #     s_1280          0.33e-4             0.52e-4           0.48e-4   -> engine vs fixture 0.60e-4 -> 0.50e-4   (control)
+    #     enh_s_128x96    1.66e-4             1.86e-4           2.00e-4   -> engine vs fixture 3.03e-4 -> 3.04e-4
+    # The engine's share WAS the larger one on the skyeye_l graphs: a single fp32 accumulator chain over K = 9 x Cin made the 3x3 layers
+    # 2.4 - 4.4 x less exact than oneDNN's (tools/fp32_layer_error.py); with partial sums every three taps they are as exact
+    # (1.4 - 1.6e-7 relative rms against 1.6 - 1.7e-7) and both cases pass at 1e-4.  The Enhanced graph's fixture is itself 1.66e-4 from
+    # the float64 result -- no fp32 implementation can be asked to sit closer to it than that --: its limit is the sum of the two
+    # measured distances from float64, 1.66e-4 + 2.00e-4 (6.1e-4 = "twice what we saw" in rounds 1 - 3).
+    return {"enh_s_128x96": 3.7e-4}.get(case["name"], 1e-4)
 
 
 def check_against_fixture(case, det, raw, tol):

@@ -105,9 +105,74 @@ def test_rccl_world1_all_gather_and_bench_step():
         assert torch.equal(r2.view(torch.int32), rows.view(torch.int32)) and torch.equal(c2, counts)
         r3, c3 = all_gather_detections(rows, counts)
         assert torch.equal(r3, rows) and torch.equal(c3, counts)
+        # BoxExchange: the NMS kernel writes the exchanged block in place (image-strided outputs through the C ABI), the block goes
+        # through the collective itself (always_collective); the captured form runs in a child process (next test)
+        from skyeye.distributed import BoxExchange
+        ex = BoxExchange(2, 300, 7, dev, always_collective=True)
+        assert ex.collective and ex.gathered.data_ptr() != ex.local.data_ptr()
+        nms_raw(det, 0.05, 0.45, max_detections=300, out=ex.rows, counts=ex.counts)
+        ar, ac = ex.gather()
+        assert torch.equal(ar.contiguous().view(torch.int32), rows.view(torch.int32)) and torch.equal(ac.contiguous(), counts)
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+_GRAPH_CHILD = r"""
+import os, socket, sys
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "skyeye-aerial-object-detection-using-yolo_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import torch.distributed as dist
+from helpers import build_detector, detector_params, variant_cfg
+from seeded import seeded_scene
+from skyeye.distributed import BoxExchange
+from skyeye.utils.metrics import nms_raw
+from skyeye.utils.torch_utils import capture_graph
+
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+m = build_detector(variant_cfg("skyeye_s"))
+m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in detector_params("skyeye_s").items()}, strict=True)
+m = m.eval().set_precision("bf16").reuse_output_buffers(True).parallel_slices(2)
+x = torch.from_numpy(seeded_scene(2, 256, 256, 11)).cuda()
+det, _ = m(x, return_raw=False)
+rows, counts = nms_raw(det.clone(), 0.05, 0.45, max_detections=300)
+ex = BoxExchange(2, 300, 7, dev, always_collective=True)
+
+def step():
+    m.detect_nms(x, 0.05, 0.45, max_detections=300, out=(ex.rows, ex.counts))
+    return ex.gather()
+
+graph, (gr, gc) = capture_graph(step, warmup=2)
+ex.local.zero_(); ex.gathered.zero_()
+graph.replay()
+torch.cuda.synchronize()
+assert int(counts.sum()) > 0
+assert torch.equal(gr.contiguous().view(torch.int32), rows.view(torch.int32)) and torch.equal(gc.contiguous(), counts)
+print("forward + NMS + RCCL all-gather replayed from one hipGraph: equal to the eager result")
+del graph, gr, gc
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("done")
+"""
+
+
+def test_rccl_all_gather_inside_a_captured_graph_world1():
+    """forward (two slices) + NMS writing the exchange block in place + the RCCL all-gather of that block, captured as ONE hipGraph and
+    replayed (world size 1, always_collective).  In a child process: tearing a communicator down around a graph that captured one of
+    its collectives aborted the interpreter once when it ran inside the suite's process."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _GRAPH_CHILD, ROOT], capture_output=True, text=True, timeout=600)
+    sys.stdout.write(r.stdout[-1500:])
+    sys.stderr.write(r.stderr[-1500:])
+    assert "replayed from one hipGraph" in r.stdout, f"child exited with {r.returncode}"
 
 
 def test_return_raw_false_skips_raw_levels_and_keeps_detections():

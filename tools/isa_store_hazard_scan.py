@@ -27,10 +27,24 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def makefile_flags():
+    """FLAGS and the per-file FLAGS_<stem> of csrc/Makefile: the scanned ISA must be the SHIPPED ISA (k_conv3x3_deep.hip is built with
+    -mllvm -pragma-unroll-threshold=200000, which unrolls its 36-step body completely and changes the schedule around the stores)."""
+    common, per = [], {}
+    for ln in open(os.path.join(CSRC, "Makefile")):
+        m = re.match(r"^FLAGS\s*:=\s*(.*)$", ln)
+        if m:
+            common = [t for t in m.group(1).split() if t not in ("-fPIC",) and "$(" not in t]
+        m = re.match(r"^FLAGS_(\w+)\s*:=\s*(.*)$", ln)
+        if m:
+            per[m.group(1)] = m.group(2).split()
+    return common, per
+
+
 def compile_asm(src, out):
-    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-I", CSRC]
-    if os.path.basename(src) in ("k_nms.hip", "k_tta.hip"):
-        flags.append("-ffp-contract=off")
+    common, per = makefile_flags()
+    stem = os.path.splitext(os.path.basename(src))[0]
+    flags = common + ["--offload-arch=gfx950", "--cuda-device-only", "-S", "-I", CSRC] + per.get(stem, [])
     subprocess.run([HIPCC] + flags + ["-o", out, src], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out
 
