@@ -44,6 +44,11 @@ __device__ __forceinline__ void fp8_unpack4(unsigned int w, float* v)
     v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
 }
 
+// bf16 engine: the bias of a convolution is the initial value of its accumulators (k_conv_halo.hip: acc_start explains); every kernel
+// that can compute a bf16 layer follows this switch, so that all of them round a sum in the same order
+template <typename T>
+struct BiasInAcc { static constexpr bool value = sizeof(T) == 2; };
+
 template <typename T>
 struct S1;
 template <>

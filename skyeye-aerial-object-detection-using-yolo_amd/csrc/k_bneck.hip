@@ -266,25 +266,26 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
             // group sg of fragment i = chunk sg >> 1, K-step sg & 1
             auto act_store = [&](const f32x4_t (&au)[4][3], int hh, int i, int sq) {
                 if (wave + 8 * i >= NFR) return;              // (uniform) waves 5..7 own two real fragments; their third is computed and dropped
-                const int sg = 2 * hh + sq;
-                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lb1 + sg * 32 + fqq * 8);
-                const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lb1 + sg * 32 + fqq * 8 + 4);
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = au[2 * sq][i][e] + c0[e];
-                    v[4 + e] = au[2 * sq + 1][i][e] + c1[e];
+                    v[e] = au[2 * sq][i][e];                     // (b1 was the accumulators' initial value)
+                    v[4 + e] = au[2 * sq + 1][i][e];
                     if (!(BK_DBG(a) & 1)) { v[e] = S1<__bf16>::silu(v[e]); v[4 + e] = S1<__bf16>::silu(v[4 + e]); }
                 }
                 Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
                 if (!inside[i]) o.a = u32x4_t{0u, 0u, 0u, 0u};
                 *reinterpret_cast<u32x4_t*>(xt + hh * CHB + (sq ? pfr[i] ^ 16 : pfr[i])) = o.a;
             };
+            // the accumulators start from the bias (k_conv_halo.hip: acc_start): fragment jj of half hh = channels (2 hh + (jj >> 1)) * 32 + fq * 8 + (jj & 1) * 4 ..
             f32x4_t au0[4][3], au1[4][3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lb1 + (j >> 1) * 32 + fqq * 8 + (j & 1) * 4);
+                const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lb1 + (2 + (j >> 1)) * 32 + fqq * 8 + (j & 1) * 4);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { au0[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; au1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+                for (int i = 0; i < 3; ++i) { au0[j][i] = c0; au1[j][i] = c1; }
+            }
             half_mma(0, au0, [](int) {});
             // step 1
             if (first) bk_wait_vm<2>(); else bk_wait_vm<8>();
@@ -321,11 +322,13 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
         // the matrix pipes idle for the whole LDS phase.  The fragments of the first two groups of step s + 1 (K-step 0 pixels, both
         // weight pairs of K-step 0) are therefore requested during the MFMAs of step s -- slab s + 1 is complete and visible since
         // the barrier of step s --, and the K-step 1 fragments of step s during its own first two groups.
-        f32x4_t acc[4][4];
+        f32x4_t acc[4][4];                                    // start from cv2's bias: fragment j = channels 64 hc + (j >> 1) * 32 + fq * 8 + (j & 1) * 4 ..
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const f32x4_t c = *reinterpret_cast<const f32x4_t*>(lb2 + 64 * hc + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) acc[j][i] = c;
+        }
         u32x4_t pf0[2][4];                                    // [step parity]: pixel fragments of K-step 0
         u32x4_t pf1[4], wq2[2], wq3[2];                       // K-step 1 pixel fragments, weight pairs of K-step 1
         int pb[13];                                           // (per tile: 40 instructions, and the registers are free during cv1)
@@ -459,12 +462,10 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 // this lane's channels of fragment pair sp: 64 hc + 32 sp + 8 fq .. + 7
-                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lb2 + 64 * hc + 32 * sp + 8 * fqe);
-                const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lb2 + 64 * hc + 32 * sp + 8 * fqe + 4);
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xx = e < 4 ? acc[2 * sp][i][e] + c0[e] : acc[2 * sp + 1][i][e - 4] + c1[e - 4];
+                    const float xx = e < 4 ? acc[2 * sp][i][e] : acc[2 * sp + 1][i][e - 4];      // (b2 was the accumulators' initial value)
                     v[e] = (BK_DBG(a) & 2) ? xx : S1<__bf16>::silu(xx);
                     if (a.c1_res) {
                         // multiply and residual add round separately, as in the 128-channel halo-tile kernel's epilogue (its residual

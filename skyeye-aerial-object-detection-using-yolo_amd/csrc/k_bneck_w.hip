@@ -218,24 +218,25 @@ __global__ void __launch_bounds__(bw::NT, 2) bneck128w_kernel(const ConvArgs a)
             };
             // u = SiLU(. + b1) -> bf16 -> back into the tile, in place: 32-channel group sg of fragment i = chunk sg >> 1, K-step sg & 1
             auto act_store = [&](const f32x4_t (&au)[4][3], int hh, int i, int sq) {
-                const int sg = 2 * hh + sq;
-                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lb1 + sg * 32 + fqq * 8);
-                const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lb1 + sg * 32 + fqq * 8 + 4);
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = S1<__bf16>::silu(au[2 * sq][i][e] + c0[e]);
-                    v[4 + e] = S1<__bf16>::silu(au[2 * sq + 1][i][e] + c1[e]);
+                for (int e = 0; e < 4; ++e) {                    // (b1 was the accumulators' initial value)
+                    v[e] = S1<__bf16>::silu(au[2 * sq][i][e]);
+                    v[4 + e] = S1<__bf16>::silu(au[2 * sq + 1][i][e]);
                 }
                 Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
                 if (!inside[i]) o.a = u32x4_t{0u, 0u, 0u, 0u};
                 if (pfr[i] >= 0) *reinterpret_cast<u32x4_t*>(xt + hh * CHB + (sq ? pfr[i] ^ 16 : pfr[i])) = o.a;
             };
+            // the accumulators start from the bias (k_conv_halo.hip: acc_start): fragment jj of half hh = channels (2 hh + (jj >> 1)) * 32 + fq * 8 + (jj & 1) * 4 ..
             f32x4_t au0[4][3], au1[4][3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lb1 + (j >> 1) * 32 + fqq * 8 + (j & 1) * 4);
+                const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lb1 + (2 + (j >> 1)) * 32 + fqq * 8 + (j & 1) * 4);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { au0[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; au1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+                for (int i = 0; i < 3; ++i) { au0[j][i] = c0; au1[j][i] = c1; }
+            }
             half_mma(0, au0, [](int) {});
             // every wave has its x fragments and residual vectors in registers behind this barrier: the tile may be rewritten
             bw_wait_barrier();
@@ -255,11 +256,13 @@ __global__ void __launch_bounds__(bw::NT, 2) bneck128w_kernel(const ConvArgs a)
         }
 
         // ---------------- steps 2 .. 19: the 3x3 over u, (chunk, tap) by (chunk, tap) ----------------
-        f32x4_t acc[4][4];
+        f32x4_t acc[4][4];                                    // start from cv2's bias: fragment j = channels 64 hc + (j >> 1) * 32 + fq * 8 + (j & 1) * 4 ..
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const f32x4_t c = *reinterpret_cast<const f32x4_t*>(lb2 + 64 * hc + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) acc[j][i] = c;
+        }
         // pixel fragment of tile row 4 pg + r (r = i + ky: 0 .. 5), column shift kx: slot = (4 pg + r) * 18 + fr + kx, address = plane +
         // slot * 32 + 16 * bit 3 of the slot; 18 = 16 + 2, so that bit is bit 3 of fr + 8 pg + c with c = 2 r + kx in 0 .. 12: thirteen
         // per-lane bases cover every tap, everything else is an immediate offset of the ds_read
@@ -351,12 +354,10 @@ __global__ void __launch_bounds__(bw::NT, 2) bneck128w_kernel(const ConvArgs a)
             const int ooff = ok ? off0 + i * a.W * a.ldo * 2 : (int)0x80000000;
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lb2 + 64 * hc + 32 * sp + 8 * fqe);
-                const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lb2 + 64 * hc + 32 * sp + 8 * fqe + 4);
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xx = e < 4 ? acc[2 * sp][i][e] + c0[e] : acc[2 * sp + 1][i][e - 4] + c1[e - 4];
+                    const float xx = e < 4 ? acc[2 * sp][i][e] : acc[2 * sp + 1][i][e - 4];      // (b2 was the accumulators' initial value)
                     v[e] = S1<__bf16>::silu(xx);
                     if (a.c1_res) {
                         // multiply and residual add round separately, as in the 128-channel halo-tile kernel's epilogue and k_bneck.hip

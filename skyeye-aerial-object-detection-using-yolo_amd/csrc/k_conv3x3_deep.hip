@@ -185,11 +185,13 @@ __global__ void __launch_bounds__(dp::NT) conv3x3_deep_kernel(const ConvArgs a)
         int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
         if (has_next) decode_item(next, nb, ny0, nx0, nn0);
         Out8<__bf16>::raw_t resv[4][2];
-        f32x4_t acc[4][4];
+        f32x4_t acc[4][4];                                    // start from the bias (k_conv_halo.hip: acc_start): fragment j = channels n0 + 64 hc + (j >> 1) * 32 + fq * 8 + (j & 1) * 4 ..
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const f32x4_t c = *reinterpret_cast<const f32x4_t*>(lbias + n0 + 64 * hc + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) acc[j][i] = c;
+        }
 
         for (int cg = 0; cg < NG; ++cg) {
             const bool last_pass = cg == NG - 1;
@@ -304,12 +306,10 @@ __global__ void __launch_bounds__(dp::NT) conv3x3_deep_kernel(const ConvArgs a)
                 const int ooff = ok ? off0 + i * a.W * a.ldo * 2 : (int)0x80000000;
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
-                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(lbias + n0 + 64 * hc + 32 * sp + 8 * fqe);
-                    const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(lbias + n0 + 64 * hc + 32 * sp + 8 * fqe + 4);
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float xx = e < 4 ? acc[2 * sp][i][e] + c0[e] : acc[2 * sp + 1][i][e - 4] + c1[e - 4];
+                        const float xx = e < 4 ? acc[2 * sp][i][e] : acc[2 * sp + 1][i][e - 4];      // (the bias was the accumulators' initial value)
                         v[e] = a.act == ACT_SILU ? S1<__bf16>::silu(xx) : xx;
                         if (has_res) {
                             // multiply and residual add round separately, as in the halo-tile kernel's 128-channel epilogue

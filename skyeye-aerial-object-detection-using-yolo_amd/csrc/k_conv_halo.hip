@@ -65,6 +65,24 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
 }
 
+// BIAS IN THE ACCUMULATOR (bf16 engine, round 4): the accumulators of a tile start as the bias of their output channels instead of zero
+// -- the first MFMA of every chain takes them as its C operand -- so the epilogue has one VALU addition per value less (of ~5.5
+// instructions per SiLU value).  The sum is then rounded as bias + k0 + k1 + ... instead of k0 + k1 + ... + bias: EVERY bf16 kernel that
+// can compute a layer does it (conv_frag.h: BiasInAcc), fused and layer-by-layer forms stay bit-identical.  fp32 (exact mode) and fp8
+// (acc * multiplier + bias) keep the addition.  Fragment j of a lane: channels (j >> 1) * 32 + fq * 8 + (j & 1) * 4 .. + 3 of the N tile.
+template <typename T, int NF>
+__device__ __forceinline__ void acc_start(f32x4_t (&acc)[NF][4], const float* lbias, int fq)
+{
+    if (BiasInAcc<T>::value) asm volatile("" : "+v"(fq));      // (opaque per tile: as loop invariants the NF bias vectors would occupy 4 NF registers for the whole kernel)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+        if (BiasInAcc<T>::value) b = *reinterpret_cast<const f32x4_t*>(lbias + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = b;
+    }
+}
+
 // Pixel `idx` (0..255, row-major) of a th x tw tile: tile-local row / column; row = -1 past the end of the tile.
 // SQ: the 16 x 16 tile, known at compile time (one fragment per tile row: constants fold into the LDS offsets).
 template <bool SQ>
@@ -138,6 +156,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     v[e] = acc[2 * s][i][e] * m0[e] + b0[e];
                     v[4 + e] = acc[2 * s + 1][i][e] * m1[e] + b1[e];
                 }
+            } else if (BiasInAcc<T>::value) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                  // the bias is the accumulators' initial value (acc_start)
+                    v[e] = acc[2 * s][i][e];
+                    v[4 + e] = acc[2 * s + 1][i][e];
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -145,6 +169,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, f32x4_t (&acc)[
                     v[4 + e] = acc[2 * s + 1][i][e] + b1[e];
                 }
             }
+            // (bf16: the next tile's acc_start overwrites the zeros with the bias.  The bias is NOT stored here: as loop-carried values the 16 x
+            // NF accumulator registers would stay live across the epilogue and the tile change, and hipcc spills 340 - 460 bytes per lane)
             acc[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             acc[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -327,9 +353,16 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             // (2) u = SiLU(W1 x + b1) on the 22 pixel fragments of the halo tile (352 slots), 6 per wave in two passes of 3
             const char* wb = w1lds + arow;
             const int k1 = 64 - 2 * (arow & 64);
+            // the tile's own accumulators hold cv2's bias here (acc_start / the epilogue): three of the four pixel columns serve as cv1's
+            // and start from cv1's bias; pass 0 leaves them at cv1's bias again, pass 1 at cv2's
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(b1lds + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[j][i] = b;
+            }
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
-                // the tile's own accumulators are zero here (cleared by the epilogue): three of the four pixel columns serve as cv1's
                 auto& au = acc;
                 u32x4_t xf[3][2];
 #pragma unroll
@@ -363,12 +396,12 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = au[2 * s][i][e] + b0[e];
-                            v[4 + e] = au[2 * s + 1][i][e] + b1[e];
+                            v[e] = au[2 * s][i][e];                         // (cv1's bias was the accumulators' initial value)
+                            v[4 + e] = au[2 * s + 1][i][e];
                             if (!(SKY_DBG(a) & 512)) { v[e] = S1<T>::silu(v[e]); v[4 + e] = S1<T>::silu(v[4 + e]); }
                         }
-                        au[2 * s][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                        au[2 * s + 1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        au[2 * s][i] = pass == 0 ? b0 : *reinterpret_cast<const f32x4_t*>(lbias + s * 32 + fq * 8);
+                        au[2 * s + 1][i] = pass == 0 ? b1 : *reinterpret_cast<const f32x4_t*>(lbias + s * 32 + fq * 8 + 4);
                         typename Out8<T>::raw_t o = Out8<T>::pack(v, 1.0f);
                         if (!inside) o.a = u32x4_t{0u, 0u, 0u, 0u};
                         if (p < HPIX && !(SKY_DBG(a) & 2048)) *reinterpret_cast<u32x4_t*>(halo + fq * HPL + p * 32 + ((s ^ ((p >> 3) & 1)) << 4)) = o.a;
@@ -459,10 +492,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, C2>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, bop);
             else tile_epilogue<T, NF, ACT_NONE, SQ, C2>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8, bop);
             f32x4_t acc2[C2 / 16][4];
-#pragma unroll
-            for (int j = 0; j < C2 / 16; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc2[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc_start<T, C2 / 16>(acc2, b2lds, fq);
             fuse_gemm<T, C2, 4>(bop, w2lds, acc2, fr, fq);
             ConvArgs a2 = a;
             a2.res = nullptr;
@@ -512,6 +542,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     int nth = 0;
     for (;;) {
         int chunk = 0, q = 0;
+        if constexpr (BiasInAcc<T>::value) acc_start<T, NF>(acc, lbias, fq);      // this tile's accumulators start from the bias
         dbg_stamp(a, stamps, nth, 0);
         if ((SKY_DBG(a) & 256) && nth == 1 && threadIdx.x == 0) stamps[60] = __builtin_amdgcn_s_memrealtime();   // 100 MHz reference clock
         if ((SKY_DBG(a) & 256) && nth == 0 && threadIdx.x == 0) { stamps[56] = __builtin_amdgcn_s_memtime(); stamps[57] = __builtin_amdgcn_s_memrealtime(); }
@@ -800,17 +831,15 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     };
 
     f32x4_t acc[NF][4];
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc_start<float, NF>(acc, lbias, fq);                          // (zeros)
 
     issue_halo(tile, 0);
     if (SRC) store_raw(0);
     int it = 0;
     for (;;) {
         wait_vmcnt0();                 // this wave's halo pieces have landed (and the previous tile's stores)
-        __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer
+        __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer (and lbias is visible)
+        if constexpr (BiasInAcc<T>::value) acc_start<T, NF>(acc, lbias, fq);      // this tile's accumulators start from the bias
         const int next = tile + gridDim.x;
         if (next < ntile) issue_halo(next, (it + 1) & 1);      // SRC: the raw loads fly under the MFMAs; converted below
         const char* hb = hlds + (it & 1) * HB;
@@ -937,10 +966,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
         }
     };
     f32x4_t acc[NF][4];
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc_start<float, NF>(acc, lbias, fq);                          // (zeros)
 
     issue_halo(tile, 0, 0);
     int u = 0;                                    // (tile, phase) counter: halo buffer u & 1
@@ -950,6 +976,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
         for (int ph = 0; ph < 4; ++ph) {
             wait_vmcnt0();
             __syncthreads();
+            if constexpr (BiasInAcc<T>::value) {
+                if (ph == 0) acc_start<T, NF>(acc, lbias, fq);   // this tile's accumulators start from the bias (lbias is visible behind the barrier)
+            }
             if (ph < 3) issue_halo(tile, ph + 1, (u + 1) & 1);
             else if (next < ntile) issue_halo(next, 0, (u + 1) & 1);
             const char* hb = hlds + (u & 1) * HB;

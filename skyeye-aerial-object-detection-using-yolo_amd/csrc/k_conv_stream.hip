@@ -123,6 +123,13 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
 #pragma unroll
         for (int i = 0; i < MF; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // bf16: the accumulators of a tile start from the bias instead of zero (k_conv_halo.hip: acc_start explains)
+    auto acc_bias = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            acc[j][i] = BiasInAcc<T>::value ? *reinterpret_cast<const f32x4_t*>(lbias + (j >> 1) * 32 + fq * 8 + (j & 1) * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+
     u32x4_t pA[MF][4], pB[MF][4];
 
     // load-side pixel state of the tile being fetched (decoded once per tile): 32-bit byte offset of the pixel's
@@ -317,6 +324,12 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                             v[e] = acc[2 * s][i][e] * m0[e] + b0[e];
                             v[4 + e] = acc[2 * s + 1][i][e] * m1[e] + b1[e];
                         }
+                    } else if (BiasInAcc<T>::value) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {          // the bias is the accumulators' initial value
+                            v[e] = acc[2 * s][i][e];
+                            v[4 + e] = acc[2 * s + 1][i][e];
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -349,15 +362,15 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                     }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc_bias(i);                                       // zeros, or the bias again (bf16)
         }
         if constexpr (FC > 0) {       // the fused 1x1: out2 = act2(W2 * packed[:, 0:FC] + b2)
             f32x4_t acc2[C2 / 16][MF];
 #pragma unroll
             for (int j = 0; j < C2 / 16; ++j)
 #pragma unroll
-                for (int i = 0; i < MF; ++i) acc2[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < MF; ++i)
+                    acc2[j][i] = BiasInAcc<T>::value ? *reinterpret_cast<const f32x4_t*>(b2lds + (j >> 1) * 32 + fq * 8 + (j & 1) * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
             fuse_gemm<T, C2, MF>(bop, w2lds, acc2, fr, fq);
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
@@ -369,8 +382,8 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = acc2[2 * s][i][e] + b2lds[nl + e];
-                            v[4 + e] = acc2[2 * s + 1][i][e] + b2lds[nl + 4 + e];
+                            v[e] = BiasInAcc<T>::value ? acc2[2 * s][i][e] : acc2[2 * s][i][e] + b2lds[nl + e];
+                            v[4 + e] = BiasInAcc<T>::value ? acc2[2 * s + 1][i][e] : acc2[2 * s + 1][i][e] + b2lds[nl + 4 + e];
                         }
                         if (a.f2_act == ACT_SILU) {
 #pragma unroll
@@ -410,6 +423,10 @@ __global__ void __launch_bounds__(SW * 64) conv_stream_kernel(const ConvArgs a)
     if (RING) {
         store_w(0);
         __syncthreads();
+    }
+    if constexpr (BiasInAcc<T>::value) {                            // lbias is visible behind the barriers above
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc_bias(i);
     }
     // one step: prefetch the next pixel slab (own registers) and, with RING, the next weight slab (other LDS stage);
     // consume `cur`.  Returns false when this wave (RING: the workgroup) is done.

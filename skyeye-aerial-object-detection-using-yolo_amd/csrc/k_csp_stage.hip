@@ -126,14 +126,17 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
         return *reinterpret_cast<const u32x4_t*>(xt + fq * XPL + p * 32 + ((kk ^ ((p >> 3) & 1)) << 4));
     };
     // 8 channels fq*8 .. +7 (+ 32 s) of this lane's pixel: fragments 2s, 2s + 1 -> bias, SiLU, bf16
-    auto act_pack = [&](const f32x4_t& a0, const f32x4_t& a1, const float* bias, float (&v)[8]) {
-        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(bias + fq * 8);
-        const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(bias + fq * 8 + 4);
+    // (the bias is the accumulators' initial value -- k_conv_halo.hip: acc_start -- : bias_pair() starts a fragment pair)
+    auto act_pack = [&](const f32x4_t& a0, const f32x4_t& a1, float (&v)[8]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = S1<__bf16>::silu(a0[e] + c0[e]);
-            v[4 + e] = S1<__bf16>::silu(a1[e] + c1[e]);
+            v[e] = S1<__bf16>::silu(a0[e]);
+            v[4 + e] = S1<__bf16>::silu(a1[e]);
         }
+    };
+    auto bias_pair = [&](const float* bias, f32x4_t& a0, f32x4_t& a1) {
+        a0 = *reinterpret_cast<const f32x4_t*>(bias + fq * 8);
+        a1 = *reinterpret_cast<const f32x4_t*>(bias + fq * 8 + 4);
     };
 
     int bimg, y0, x0;
@@ -152,18 +155,20 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
             const int p = f * 16 + fr;
             const int pc = p < NHP ? p : NHP - 1;                 // past the tile: any valid pixel, never stored
             const u32x4_t x0f = xfrag(pc, 0), x1f = xfrag(pc, 1);
-            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t acc0, acc1;
+            bias_pair(b12, acc0, acc1);
             S1<__bf16>::mma(wfrag(w12, C, 0, 0), x0f, acc0);
             S1<__bf16>::mma(wfrag(w12, C, 0, 1), x0f, acc1);
             S1<__bf16>::mma(wfrag(w12, C, 1, 0), x1f, acc0);
             S1<__bf16>::mma(wfrag(w12, C, 1, 1), x1f, acc1);
             float v[8];
-            act_pack(acc0, acc1, b12, v);
+            act_pack(acc0, acc1, v);
             const Out8<__bf16>::raw_t y1v = Out8<__bf16>::pack(v, 1.0f);
-            f32x4_t au0 = {0.f, 0.f, 0.f, 0.f}, au1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t au0, au1;
+            bias_pair(bb1, au0, au1);
             S1<__bf16>::mma(wfrag(wb1, HD, 0, 0), y1v.a, au0);
             S1<__bf16>::mma(wfrag(wb1, HD, 0, 1), y1v.a, au1);
-            act_pack(au0, au1, bb1, v);
+            act_pack(au0, au1, v);
             Out8<__bf16>::raw_t uv = Out8<__bf16>::pack(v, 1.0f);
             const int hy = (pc * 3641) >> 16, hx = pc - hy * HW;
             const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)a.H && (unsigned)(x0 - 1 + hx) < (unsigned)a.W;
@@ -179,13 +184,14 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
             const int r = 2 * wave + i;
             const int p = (r + 1) * HW + 1 + fr;
             const u32x4_t x0f = xfrag(p, 0), x1f = xfrag(p, 1);
-            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t acc0, acc1;
+            bias_pair(b12 + HD, acc0, acc1);
             S1<__bf16>::mma(wfrag(w12, C, 0, 2), x0f, acc0);
             S1<__bf16>::mma(wfrag(w12, C, 0, 3), x0f, acc1);
             S1<__bf16>::mma(wfrag(w12, C, 1, 2), x1f, acc0);
             S1<__bf16>::mma(wfrag(w12, C, 1, 3), x1f, acc1);
             float v[8];
-            act_pack(acc0, acc1, b12 + HD, v);
+            act_pack(acc0, acc1, v);
             *reinterpret_cast<u32x4_t*>(y2t + fq * CPLN + (r * 16 + fr) * 16) = Out8<__bf16>::pack(v, 1.0f).a;
         }
         __syncthreads();                                          // u, y1, y2 complete; x is dead
@@ -199,9 +205,7 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
         {
             f32x4_t acc[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 2; ++i) bias_pair(bb2, acc[0][i], acc[1][i]);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -217,9 +221,9 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
             }
             f32x4_t acc3[4][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc3[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 2; ++i) bias_pair(b3 + s * 32, acc3[2 * s][i], acc3[2 * s + 1][i]);
             u32x4_t vv[2], y2v[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -229,17 +233,15 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
                     // hipcc contracts the activation's last multiply with the residual add of the layer-by-layer epilogue into one fma
                     // (tile_epilogue, k_conv_halo.hip); written out here so that both forms round alike
                     const Out8<__bf16>::raw_t rv = Out8<__bf16>::load(y1t + fq * HPLN + ((r + 1) * HW + 1 + fr) * 16);
-                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(bb2 + fq * 8);
-                    const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(bb2 + fq * 8 + 4);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float xx = e < 4 ? acc[0][i][e] + c0[e] : acc[1][i][e - 4] + c1[e - 4];
+                        const float xx = e < 4 ? acc[0][i][e] : acc[1][i][e - 4];
                         const float t = S1<__bf16>::gate(xx);
                         const float res = (e & 1) ? __uint_as_float(rv.a[e >> 1] & 0xffff0000u) : __uint_as_float(rv.a[e >> 1] << 16);
                         v[e] = __builtin_fmaf(xx, t, res);
                     }
                 } else {
-                    act_pack(acc[0][i], acc[1][i], bb2, v);
+                    act_pack(acc[0][i], acc[1][i], v);
                 }
                 vv[i] = Out8<__bf16>::pack(v, 1.0f).a;
                 y2v[i] = *reinterpret_cast<const u32x4_t*>(y2t + fq * CPLN + (r * 16 + fr) * 16);
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         float v[8];
-                        act_pack(acc3[2 * s][i], acc3[2 * s + 1][i], b3 + s * 32, v);
+                        act_pack(acc3[2 * s][i], acc3[2 * s + 1][i], v);
                         Out8<__bf16>::store(Out8<__bf16>::pack(v, 1.0f), op + (s * 32 + fq * 8) * 2);
                     }
                 }

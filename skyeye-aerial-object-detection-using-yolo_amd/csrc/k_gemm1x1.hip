@@ -205,6 +205,17 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
     __syncthreads();                                           // bias visible (drains the first pieces too: once)
 
     int c_item = L, c_k = 0;
+    // the accumulators of an item start from the bias of ITS N tile (k_conv_halo.hip: acc_start explains; this kernel is bf16 only)
+    auto acc_bias = [&](int item) {
+        const int nb0 = (item % gy) * TN + wn * (NFJ * 16) + fq * 8;
+#pragma unroll
+        for (int j = 0; j < NFJ; ++j) {
+            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(lbias + nb0 + (j >> 1) * 32 + (j & 1) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = b;
+        }
+    };
+    acc_bias(c_item);
     int after_epi = 0;                                         // steps since an epilogue whose stores are still counted (0: none)
     int stage = 0;
     for (int g = 0; g < total; ++g) {
@@ -263,14 +274,11 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
                 }
 #pragma unroll
                 for (int sg = 0; sg < NFJ / 2; ++sg) {
-                    const int nl = n0 + sg * 32 + fq * 8;
-                    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl);
-                    const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[2 * sg][i][e] + b0[e];
-                        v[4 + e] = acc[2 * sg + 1][i][e] + b1[e];
+                    for (int e = 0; e < 4; ++e) {                  // (the bias was the accumulators' initial value)
+                        v[e] = acc[2 * sg][i][e];
+                        v[4 + e] = acc[2 * sg + 1][i][e];
                     }
                     if (a.act == ACT_SILU && !G1_OFF(4)) {
 #pragma unroll
@@ -282,12 +290,11 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
                     if (RES) Out8<__bf16>::add(rres[i & 1][sg], v, a.res_scale);
                     const Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
                     Out8<__bf16>::store(o, orsrc, obase < 0 ? -1 : obase + sg * 64);      // (always issued: the waits count it)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) acc[2 * sg + h][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 }
             }
             c_k = 0;
             c_item += G;
+            acc_bias(c_item);                                  // (past the last item: a valid N tile's bias, never used)
             after_epi = 1;
         }
     }

@@ -284,11 +284,13 @@ __global__ void __launch_bounds__(hd::NT) cv3_head_kernel(const ConvArgs a)
     for (int g = g_first; g < ngroups; g += g_step) {
         const int m0 = g * (MF * 16);
         // ---- cv3: 128 -> 128 over 4 K-steps ----
-        f32x4_t acc1[8][MF];
+        f32x4_t acc1[8][MF];                                      // start from cv3's bias (k_conv_halo.hip: acc_start): fragment j = channels (j >> 1) * 32 + fq * 8 + (j & 1) * 4 ..
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
+            const f32x4_t c = *reinterpret_cast<const f32x4_t*>(lb3 + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
 #pragma unroll
-            for (int i = 0; i < MF; ++i) acc1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MF; ++i) acc1[j][i] = c;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS4; ++ks) {
 #pragma unroll
@@ -307,13 +309,11 @@ __global__ void __launch_bounds__(hd::NT) cv3_head_kernel(const ConvArgs a)
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) {
                 const int nl = sg * 32 + fq * 8;
-                const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lb3 + nl);
-                const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(lb3 + nl + 4);
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc1[2 * sg][i][e] + b0[e];
-                    v[4 + e] = acc1[2 * sg + 1][i][e] + b1[e];
+                for (int e = 0; e < 4; ++e) {                      // (cv3's bias was the accumulators' initial value)
+                    v[e] = acc1[2 * sg][i][e];
+                    v[4 + e] = acc1[2 * sg + 1][i][e];
                 }
                 if (a.act == ACT_SILU) {                       // (ACT_NONE: the head-attention variant's output projection, attention.py:312-399)
 #pragma unroll

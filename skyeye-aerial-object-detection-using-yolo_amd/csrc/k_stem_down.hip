@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
                 if (p >= SS * SS) p = SS * SS - 1;                // past the tile: any valid pixel, never stored
                 const int sy = p / SS, sx = p - sy * SS;
                 pb[i] = (sy * HS + sx) * 16;
-                acc[0][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                acc[1][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                acc[0][i] = bia0;                                 // the accumulators start from the bias (k_conv_halo.hip: acc_start)
+                acc[1][i] = bia1;
             }
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
@@ -236,8 +236,8 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = S1<__bf16>::silu(acc[0][i][e] + bia0[e]);
-                    v[4 + e] = S1<__bf16>::silu(acc[1][i][e] + bia1[e]);
+                    v[e] = S1<__bf16>::silu(acc[0][i][e]);
+                    v[4 + e] = S1<__bf16>::silu(acc[1][i][e]);
                 }
                 Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
                 if (!inside) o.a = u32x4_t{0u, 0u, 0u, 0u};                       // the stride-2 convolution's zero padding
@@ -259,11 +259,13 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
 
         // ---- phase C: stride-2 convolution, tile rows 2 * wave and 2 * wave + 1 ----
         {
-            f32x4_t acc[4][2];
+            f32x4_t acc[4][2];                                    // start from the bias: fragment j = channels (j >> 1) * 32 + fq * 8 + (j & 1) * 4 ..
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t c = *reinterpret_cast<const f32x4_t*>(b2 + (j >> 1) * 32 + fq * 8 + (j & 1) * 4);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 2; ++i) acc[j][i] = c;
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -289,13 +291,11 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
                     char* op = reinterpret_cast<char*>(a.out) + (((long)bimg * a.Ho + oy) * a.Wo + ox) * (long)a.ldo * 2;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const f32x4_t bia0 = *reinterpret_cast<const f32x4_t*>(b2 + s * 32 + fq * 8);
-                        const f32x4_t bia1 = *reinterpret_cast<const f32x4_t*>(b2 + s * 32 + fq * 8 + 4);
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = S1<__bf16>::silu(acc[2 * s][i][e] + bia0[e]);
-                            v[4 + e] = S1<__bf16>::silu(acc[2 * s + 1][i][e] + bia1[e]);
+                            v[e] = S1<__bf16>::silu(acc[2 * s][i][e]);
+                            v[4 + e] = S1<__bf16>::silu(acc[2 * s + 1][i][e]);
                         }
                         Out8<__bf16>::store(Out8<__bf16>::pack(v, 1.0f), op + (s * 32 + fq * 8) * 2);
                     }

@@ -122,8 +122,9 @@ def test_bf16_vs_fp32_engine_post_nms_at_b32_1280():
     # weights held times 1.0 / 1.2 / log2 e / 1.7 (profiles/r04_pre_scale_eval.jsonl, skyeye_s @1280: rows with IoU > 0.9 against the
     # fp32 engine 0.915 / 0.850 / 0.884 / 0.910, relative L2 of the logits 0.0142 / 0.0190 / 0.0170 / 0.0164): the strict IoU-0.9 rate
     # is the statistic that moves; per-layer errors are unchanged (tools: a 576-deep layer emulated both ways, rms 3.1e-3 either way).
-    # Floors: IoU 0.5 and mean IoU as before, IoU 0.9 at 0.9 x the round-4 value.
-    assert m50 > 0.88 and m90 > 0.59 and miou > 0.9, (m50, m90, miou)
+    # With the bias in the accumulator on top (a sum rounds as b + k0 + .. instead of k0 + .. + b): 0.906 / 0.644 / 0.912.
+    # Floors: 0.8 x the worst IoU-0.9 rate seen, IoU 0.5 and mean IoU 0.03 below the worst.
+    assert m50 > 0.875 and m90 > 0.515 and miou > 0.88, (m50, m90, miou)
 
 
 def test_views_of_2gib_and_more_run_as_batch_slices():
