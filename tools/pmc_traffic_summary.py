@@ -32,6 +32,8 @@ for k, v in agg.items():
         variant = 8064
     elif "csp_stage_kernel" in k:
         variant = 8564
+    elif "bneck128w" in k:
+        variant = 7256
     elif "bneck128" in k:
         variant = 7128
     elif "conv3x3_deep_kernel" in k:
