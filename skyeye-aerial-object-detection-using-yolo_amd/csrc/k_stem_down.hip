@@ -83,6 +83,27 @@ __device__ __forceinline__ void sd_stage_weights(const void* w, int kpad, int kb
     }
 }
 
+// Stem pixel (sy, sx) of lane `fr` of pixel fragment f (round 4).  The 33 x 33 stem pixels were walked row-major, 16 per fragment: every second
+// fragment then wraps from one tile row into the next and its 16 B operands are no longer one contiguous 256-byte run of the 35-pixel-wide
+// space-to-depth tile -- 31 % of the LDS cycles of the stem GEMM's pixel reads were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.205 for the kernel in rounds 2 and 3).  Now fragments 0 .. 65 are the two aligned halves of a row (columns 0 .. 15, 16 .. 31) and fragments
+// 66 .. 68 walk column 32 downwards (pixels 560 bytes apart: 16 lanes on 16 distinct bank quads): the same 69 fragments, every read conflict-free.
+// Returns false for a lane that holds no stem pixel (rows past 32 of the column fragments, fragments past 68); (sy, sx) is then a valid pixel.
+__device__ __forceinline__ bool stem_pixel(int f, int fr, int& sy, int& sx)
+{
+    using namespace sd;
+    if (f < 2 * SS) {
+        sy = f >> 1;
+        sx = (f & 1) * 16 + fr;
+        return true;
+    }
+    sy = (f - 2 * SS) * 16 + fr;
+    sx = SS - 1;
+    const bool real = f < NPF && sy < SS;
+    if (!real) sy = SS - 1;
+    return real;
+}
+
 __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
 {
     using namespace sd;
@@ -207,9 +228,8 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
             int pb[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                int p = (wave * PFW + g3 * 3 + i) * 16 + fr;
-                if (p >= SS * SS) p = SS * SS - 1;                // past the tile: any valid pixel, never stored
-                const int sy = p / SS, sx = p - sy * SS;
+                int sy, sx;
+                stem_pixel(wave * PFW + g3 * 3 + i, fr, sy, sx);  // (past the tile: a valid pixel, never stored)
                 pb[i] = (sy * HS + sx) * 16;
                 acc[0][i] = bia0;                                 // the accumulators start from the bias (k_conv_halo.hip: acc_start)
                 acc[1][i] = bia1;
@@ -229,8 +249,8 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
         auto act3 = [&](int g3, const f32x4_t (&acc)[2][3]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int p = (wave * PFW + g3 * 3 + i) * 16 + fr;
-                const int sy = p / SS, sx = p - sy * SS;
+                int sy, sx;
+                const bool real = stem_pixel(wave * PFW + g3 * 3 + i, fr, sy, sx);
                 const int gy = 2 * y0 - 1 + sy, gx = 2 * x0 - 1 + sx;            // stem pixel in the 640 x 640 map
                 const bool inside = (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;
                 float v[8];
@@ -243,7 +263,7 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
                 if (!inside) o.a = u32x4_t{0u, 0u, 0u, 0u};                       // the stride-2 convolution's zero padding
                 const int par = (sy & 1) * 2 + (sx & 1);
                 const int cell = (sy >> 1) * ppitch(par) + (sx >> 1);
-                if (p < SS * SS) *reinterpret_cast<u32x4_t*>(stem + pbase(par) + fq * (pcells(par) * 16) + cell * 16) = o.a;
+                if (real) *reinterpret_cast<u32x4_t*>(stem + pbase(par) + fq * (pcells(par) * 16) + cell * 16) = o.a;
             }
         };
         {
