@@ -13,7 +13,13 @@ the capturing caller's stream -- and NOTHING orders their tails before the calle
 pairs and explicit events kept alive alike" failed.  The ROCm 7.0 runtime of this image dereferences the unjoined capture in
 hipStreamEndCapture instead of returning the error.  ``join=True`` adds the one missing edge (caller waits for the NMS stream, whose
 tail is behind every slice's last forward pass) and is a legal capture; ``capture_graph`` now refuses the ``join=False`` form with a
-Python error before the runtime sees it (tests/test_gpu_capture_guard.py)."""
+Python error before the runtime sees it (tests/test_gpu_capture_guard.py).
+
+Round 4, second finding (experiments/stagger_probe.py): with THREE or more batches this function makes the slice streams wait for the NMS
+stream (the forward pass of batch k re-uses the detection buffer the NMS of batch k - 2 read) while the NMS stream waits for the slice
+streams -- mutual waits between two forked streams.  That DAG is legal and, with ``join=True``, joined; hipStreamEndCapture faults on it all
+the same (8-step chain, faulthandler: torch/cuda/graphs.py capture_end).  With one detection buffer per step (no back edge) the same
+8-step chain captures and replays.  ``CaptureLedger.wait`` flags the back edge before it is made and ``capture_graph`` refuses it."""
 import torch
 
 
@@ -34,8 +40,8 @@ def detect_nms_chain(model, batches, conf=0.25, iou=0.45, max_detections=300, jo
     cur = torch.cuda.current_stream(dev)
     ents = [model._engine_entry([x0[i * half:(i + 1) * half]], None, slot=i + 1)[1] for i in range(nsl)]
     shapes = ents[0].output_shapes()
-    if st.get("B") != (B, max_detections):
-        st["B"] = (B, max_detections)
+    if st.get("B") != (B, max_detections, len(batches)):
+        st["B"] = (B, max_detections, len(batches))
         st["det"] = [torch.empty((B,) + tuple(shapes[0][1:]), dtype=torch.float32, device=dev) for _ in range(2)]
         st["out"] = [(torch.empty((B, max_detections, 7), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev))
                      for _ in range(len(batches))]

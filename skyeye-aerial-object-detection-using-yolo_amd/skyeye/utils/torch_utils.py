@@ -65,6 +65,11 @@ class CaptureLedger:
     experiments/detect_nms_chain.py -- slice and NMS streams ordered among themselves, never back into the origin).  The ledger
     finds the unjoined streams BEFORE the capture ends, so ``capture_graph`` can join them, end the capture legally and raise.
 
+    A second shape faults in ``hipStreamEndCapture`` although it is a legal DAG and fully joined (round 4, experiments/stagger_probe.py:
+    an 8-step chain whose slice streams wait for the NMS stream's events while the NMS stream waits for theirs): MUTUAL waits between two
+    forked streams.  With one detection buffer per step -- no slice stream ever waits for the NMS stream -- the same chain captures and
+    replays.  ``wait`` returns a message for such an edge BEFORE it is made, so that the caller can refuse it.
+
     What it is told: ``record(s)`` -> event token (the tail of stream s at this moment), ``wait(s, token)``.  Kernel launches are not
     seen; every record or wait on a stream counts as new activity on it, which is what a launch between them would be."""
 
@@ -86,6 +91,12 @@ class CaptureLedger:
                 self.problems.append(f"capturing stream {s!r} waits for an event recorded outside the capture on stream {src!r} "
                                      "(a dependency across the capture boundary: StreamCaptureIsolation)")
             return
+        fatal = None
+        if s != self.origin and src != self.origin and self.cover.get(src, {}).get(s, 0) > 0:
+            fatal = (f"forked stream {s!r} waits for forked stream {src!r}, which has itself waited for {s!r}: mutual waits between two forked "
+                     "streams make this runtime's hipStreamEndCapture fault (a legal DAG; order such work through the capturing stream, or give "
+                     "every step its own buffers so that the back edge is not needed)")
+            self.problems.append(fatal)
         self.captured.add(s)
         self.seq[s] = self.seq.get(s, 0) + 1
         c = self.cover.setdefault(s, {})
@@ -94,6 +105,7 @@ class CaptureLedger:
                 c[k] = v
         if c.get(src, 0) < n:
             c[src] = n
+        return fatal
 
     def unjoined(self):
         """Streams that joined the capture and whose tail is not ordered before the origin's tail."""
@@ -124,7 +136,9 @@ class _LedgerPatch:
             st = stream if stream is not None else torch.cuda.current_stream()
             streams[st.cuda_stream] = st
             if id(self_) in tokens:
-                L.wait(st.cuda_stream, tokens[id(self_)][1])
+                fatal = L.wait(st.cuda_stream, tokens[id(self_)][1])
+                if fatal:                                 # refused BEFORE the edge exists: the capture can still end legally
+                    raise N.SkyEyeNativeError("capture_graph: " + fatal)
             return wai(self_, st)
 
         E.record, E.wait = ev_record, ev_wait

@@ -47,15 +47,18 @@ def test_round3_chain_is_an_unjoined_capture():
     for n in (2, 4):
         L = CaptureLedger("cur")
         _chain(L, n, join=False)
-        assert sorted(L.unjoined()) == ["nms", "s0", "s1"] and not L.problems
+        assert sorted(L.unjoined()) == ["nms", "s0", "s1"]
+        assert bool(L.problems) == (n > 2)              # from the third step on the two-buffer chain also has the mutual waits (below)
 
 
 def test_chain_with_the_final_join_is_legal():
     """One edge (caller waits for the NMS stream) orders every tail before the caller: the slices' last work is behind the last NMS."""
-    for n in (2, 4):
-        L = CaptureLedger("cur")
-        _chain(L, n, join=True)
-        assert L.unjoined() == [] and not L.problems
+    L = CaptureLedger("cur")
+    _chain(L, 2, join=True)
+    assert L.unjoined() == [] and not L.problems
+    L = CaptureLedger("cur")
+    _chain(L, 4, join=True)                             # joined, and still refused: slice streams wait for the NMS stream and vice versa
+    assert L.unjoined() == [] and L.problems and "mutual waits" in L.problems[0]
 
 
 def test_work_after_the_join_needs_another_join():
@@ -74,3 +77,24 @@ def test_wait_for_an_event_from_outside_the_capture():
     L2 = CaptureLedger("cur")
     L2.wait("elsewhere", L2.record("other"))        # two streams outside the capture: none of the ledger's business
     assert not L2.problems and L2.captured == {"cur"}
+
+
+def test_mutual_waits_between_forked_streams_are_flagged_before_the_edge_is_made():
+    """Round 4 (experiments/stagger_probe.py): an 8-step chain with two detection buffers -- slice streams wait for the NMS of batch k - 2,
+    the NMS stream waits for the slices -- is joined and legal, and this runtime's hipStreamEndCapture faults on it."""
+    L = CaptureLedger("cur")
+    for s in ("s0", "s1"):
+        _wait(L, s, "cur")
+    for k in range(2):
+        for s in ("s0", "s1"):
+            assert L.wait("nms", L.record(s)) is None        # forward edges only (slices -> NMS): fine
+    msg = L.wait("s0", L.record("nms"))                      # the first back edge (k = 2): the slice stream waits for the NMS stream
+    assert msg and "mutual waits" in msg and L.problems == [msg]
+    # the shipped topologies have no edge between two forked streams at all
+    L2 = CaptureLedger("cur")
+    _wait(L2, "nms", "cur")
+    for s in ("s0", "s1"):
+        _wait(L2, s, "cur")
+        _wait(L2, "cur", s)
+    _wait(L2, "cur", "nms")
+    assert not L2.problems

@@ -50,6 +50,17 @@ torch.cuda.synchronize()
 for (r, c), (r0, c0) in zip(outs, want):
     assert torch.equal(c, c0) and torch.equal(r, r0)
 print("chain with join: captured, replayed, equal to detect_nms")
+
+# (3) three batches through TWO detection buffers: the forward pass of batch 2 waits for the NMS of batch 0 (its buffer) while the NMS stream
+# waits for the slices -- joined, legal, and this runtime's hipStreamEndCapture faults on it (round 4): refused before the edge is made
+xs3 = xs + [xs[0]]
+try:
+    capture_graph(lambda: detect_nms_chain(m, xs3, join=True), warmup=1)
+    print("NOT REFUSED (3)"); sys.exit(4)
+except N.SkyEyeNativeError as e:
+    assert "mutual waits" in str(e), str(e)
+    print("refused (mutual):", str(e)[:120])
+torch.cuda.synchronize()
 """
 
 
@@ -58,4 +69,4 @@ def test_unjoined_capture_is_refused_and_the_joined_chain_replays():
     sys.stdout.write(r.stdout[-2000:])
     sys.stderr.write(r.stderr[-2000:])
     assert r.returncode == 0, f"child exited with {r.returncode}"
-    assert "refused:" in r.stdout and "chain with join" in r.stdout
+    assert "refused:" in r.stdout and "chain with join" in r.stdout and "refused (mutual):" in r.stdout
