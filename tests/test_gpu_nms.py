@@ -93,3 +93,39 @@ def test_nms_without_candidates_returns_empty_rows():
     pred = make_predictions(4, 3, 2000, 5)
     res = non_max_suppression(torch.from_numpy(pred).cuda(), conf_threshold=2.0, iou_threshold=0.5)       # nothing passes
     assert [int(r.shape[0]) for r in res] == [0, 0, 0]
+
+
+def test_nms_strided_outputs_and_the_round3_struct():
+    """sky_nms_params ends in out_image_stride / counts_stride (round 4): rows and counts written with an image stride (the blocks of a
+    skyeye.distributed.BoxExchange) are the dense result bit for bit, the gaps between the blocks stay untouched; a caller built against the
+    round-3 struct (recognised by struct_size) still gets dense outputs; strides below the dense sizes are refused."""
+    import ctypes
+    from skyeye import _native as N
+    from skyeye.distributed import BoxExchange
+    from skyeye.utils.metrics import _handle, nms_raw
+    pred = torch.from_numpy(make_predictions(5, 4, 3000, 99)).cuda()
+    rows, counts = nms_raw(pred, 0.2, 0.45, max_detections=50)
+    ex = BoxExchange(4, 50, 7, "cuda")
+    ex.local.fill_(-7)
+    nms_raw(pred, 0.2, 0.45, max_detections=50, out=ex.rows, counts=ex.counts)
+    assert torch.equal(ex.rows.contiguous().view(torch.int32), rows.view(torch.int32)) and torch.equal(ex.counts.contiguous(), counts)
+    assert ex.local.shape == (4, 351) and int(counts.sum()) > 0
+    # a batch slice of the strided views (what detect_nms hands to a slice's NMS)
+    ex.local.fill_(-7)
+    nms_raw(pred[2:], 0.2, 0.45, max_detections=50, out=ex.rows[2:], counts=ex.counts[2:])
+    assert torch.equal(ex.rows[2:].contiguous().view(torch.int32), rows[2:].view(torch.int32)) and bool((ex.local[:2] == -7).all())
+    # the round-3 struct: everything up to `classes`, struct_size says so
+    p = N.SkyNmsParams()
+    p.struct_size = N.SkyNmsParams.out_image_stride.offset
+    p.conf_threshold, p.iou_threshold, p.max_detections, p.max_nms, p.max_wh, p.mode = 0.2, 0.45, 50, 30000, 4096.0, 0
+    p.out_image_stride, p.counts_stride = 12345, 77          # (behind the declared size: must be ignored)
+    out = torch.empty((4, 50, 7), dtype=torch.float32, device="cuda")
+    cnt = torch.empty((4,), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    h = _handle(0, stream)
+    N.check(h.L.sky_nms(h.h, pred.data_ptr(), 4, 3000, 5, ctypes.byref(p), out.data_ptr(), cnt.data_ptr(), ctypes.c_void_p(stream)), h.h)
+    assert torch.equal(out.view(torch.int32), rows.view(torch.int32)) and torch.equal(cnt, counts)
+    p.struct_size = ctypes.sizeof(N.SkyNmsParams)
+    p.out_image_stride, p.counts_stride = 50 * 7 - 1, 1
+    with pytest.raises(N.SkyEyeNativeError):
+        N.check(h.L.sky_nms(h.h, pred.data_ptr(), 4, 3000, 5, ctypes.byref(p), out.data_ptr(), cnt.data_ptr(), ctypes.c_void_p(stream)), h.h)

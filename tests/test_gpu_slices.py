@@ -124,3 +124,29 @@ def test_unequal_slices_equal_whole_batch():
     assert torch.equal(c0, c1) and torch.equal(r0, r1)
     y = torch.from_numpy(seeded_scene(6, 256, 320, 34)).cuda()          # another batch size: not sliced, still right
     assert torch.equal(_model()(y)[0], sl(y)[0])
+
+
+def test_fp8_slices_need_calibration_frames_of_the_slices_geometry():
+    """fp8 plans take their activation scales from the frames given to ``calibrate()`` -- when those have the plan's geometry.  Calibrated at
+    ANOTHER resolution, every slice plan would fall back to calibrating itself on its own half of the batch (other scales than the whole
+    batch: results that depend on the batch's composition).  ``_sliceable`` applies ``_engine_entry``'s predicate, so such a call takes the
+    whole-batch plan: bit-identical to the unsliced module; with matching calibration frames the slices run and are bit-identical too."""
+    x = torch.from_numpy(seeded_scene(8, 320, 320, 41)).cuda()
+    other = torch.from_numpy(seeded_scene(4, 256, 256, 42)).cuda()
+    ref = _model("fp8")
+    ref.calibrate(other)                                     # (not used by a 320 x 320 plan: it calibrates itself on the whole batch)
+    d0, _ = ref(x, return_raw=False)
+    sl = _model("fp8").parallel_slices(2)
+    sl.calibrate(other)
+    assert not sl._sliceable([sl._prepare_input(x)], 2)
+    d1, _ = sl(x, return_raw=False)
+    assert torch.equal(d0, d1)
+    # matching geometry: common scales for both slices, sliced == whole batch
+    ref2 = _model("fp8")
+    ref2.calibrate(x[:4])
+    e0, _ = ref2(x, return_raw=False)
+    sl2 = _model("fp8").parallel_slices(2)
+    sl2.calibrate(x[:4])
+    assert sl2._sliceable([sl2._prepare_input(x)], 2)
+    e1, _ = sl2(x, return_raw=False)
+    assert torch.equal(e0, e1)
