@@ -172,6 +172,10 @@ struct Engine {
 
     bool calibrated = false;    // fp8: activation scales are set
     unsigned mask_opts = 0;     // PlanOpt bits this plan must not take from the environment (the calibration twin of an fp8 plan)
+    // the calibration twin of an fp8 plan: element type and PlanOpt bits of the plan it measures for.  Decisions that change the BUFFER LIST (a small
+    // lateral map read in place by its consumer, ConvArgs::in2) are taken as that plan takes them; the twin then materialises the tensor anyway
+    int mirror_dtype = -1;
+    unsigned mirror_opts = 0;
     int esize() const { return dtype_size(dtype); }
     int epc() const { return 16 / dtype_size(dtype); }
     void free_plan()
@@ -972,26 +976,33 @@ static void neck(Ctx& c, const std::string& p, const NeckSlots& n, int c3, int c
     const TV &p3 = n.p3, &p4 = n.p4, &p5 = n.p5;
     // would the CSP's fused cv1 | cv2 GEMM read the upsampled half of its input from the small lateral map itself (conv_accepts_in2)?
     auto reads_small = [&](const TV& cat, int c_lat, int hidden2) {
-        if (!c.emit || (c.e.dtype != SKY_BF16 && c.e.dtype != SKY_F32) || (c.e.opts & OPT_NO_IN2)) return false;
+        const int dt = c.e.mirror_dtype >= 0 ? c.e.mirror_dtype : (int)c.e.dtype;          // (the twin of an fp8 plan asks for THAT plan)
+        const unsigned opts = c.e.mirror_dtype >= 0 ? c.e.mirror_opts : c.e.opts;
+        if (!c.emit || (opts & OPT_NO_IN2)) return false;
         ConvArgs a;
         memset(&a, 0, sizeof(a));
-        const int esz = dtype_size(c.e.dtype);
+        const int esz = dtype_size(dt);
         a.B = cat.B; a.H = cat.H; a.W = cat.W; a.Ho = cat.H; a.Wo = cat.W; a.Cin = cat.C; a.Cout = hidden2; a.ldi = cat.ld; a.ldo = hidden2;
         a.ks = 1; a.stride = 1; a.act = ACT_SILU; a.M = cat.B * cat.H * cat.W; a.out_dt = -1;
-        a.Kpad = (cat.C + conv_k_step(c.e.dtype) - 1) / conv_k_step(c.e.dtype) * conv_k_step(c.e.dtype);
-        a.opts = c.e.opts; a.device = c.e.cfg.device; a.n_cu = c.e.n_cu;
+        a.Kpad = (cat.C + conv_k_step(dt) - 1) / conv_k_step(dt) * conv_k_step(dt);
+        a.opts = opts; a.device = c.e.cfg.device; a.n_cu = c.e.n_cu;
         a.in2 = &a; a.in2_cin = c_lat; a.ldi2 = c_lat; a.in2_up2 = 1;
         const double ext = ((double)a.M - 1.0) * cat.ld * esz + (double)cat.C * esz;
         a.in_bytes = a.in2_bytes = a.out_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;
-        return conv_accepts_in2(c.e.dtype, a);
+        return conv_accepts_in2(dt, a);
     };
     // returns the small lateral map when the consumer reads it directly (then the slot's half of the concat buffer stays unwritten)
     auto lateral = [&](const std::string& name, const TV& x, int cin, int cout, const TV& cat, int Ht, int Wt, int hidden2, TV& small) {
         const TV slot = Ctx::slice(cat, 0, cout);
         if (Ht == 2 * x.H && Wt == 2 * x.W && reads_small(cat, cout, hidden2)) {
+            // fp8: the small map carries the concat buffer's scale (one multiplier per output channel covers both parts of K)
             small = conv_block(c, p + name, x, cin, cout, 1, 1, true);
             c.tie_scales(small.buf, cat.buf);
-            return true;
+            if (c.e.mirror_dtype < 0) return true;
+            Op u;                               // calibration twin: the same buffers as the plan it measures for, every tensor written
+            u.kind = OP_UPSAMPLE; u.in = small; u.out = slot;
+            c.push(u);
+            return false;
         }
         if (Ht == 2 * x.H && Wt == 2 * x.W) {   // exact 2x: upsample in the epilogue
             ConvOpt o;
@@ -1871,6 +1882,8 @@ static void calibrate(Engine& e, int n_inputs, const sky_buffer* inputs, hipStre
     tw.dtype = SKY_BF16;
     tw.weights = e.weights;
     tw.extra_opts = OPT_NO_FUSE_CV1 | OPT_NO_STEM_DOWN | OPT_NO_CSP_STAGE | OPT_NO_IN2;      // same buffer list as the fp8 plan (fused bottlenecks add scratch tensors), every tensor materialised
+    tw.mirror_dtype = SKY_FP8;          // ... including the small lateral maps that plan's CSP GEMMs read in place (neck(): lateral)
+    tw.mirror_opts = e.opts;
     tw.mask_opts = OPT_FUSE;            // like the fp8 plan itself: an op computed in its producer's epilogue would never reach its amax reduction
     plan(tw, geometry_of(n_inputs, inputs));
     if (tw.bufs.size() != e.bufs.size()) throw Error(SKY_ERR_STATE, "sky_calibrate: the bf16 twin has another buffer list than the fp8 plan");

@@ -94,26 +94,33 @@ __device__ __forceinline__ void g1_wait(int younger, bool st)
 
 // RES: a residual (ConvArgs::res, the output's element type) is added behind the activation (TransformerLayer's x + proj(..) / x + ffn(..),
 // reference attention.py:244-309); its 16-byte vectors are loaded one pixel fragment ahead, the first four under the tile's last MFMAs
-template <typename GEO, bool RES>
+// T = __bf16, or fp8_t (round 4; config 5's engine): the same 128-byte rows hold 128 channels, both 64-byte halves of a row go into ONE
+// 16x16x128 block-scaled instruction (fp8_mma128: the pairing of K-steps conv_stream_kernel's fp8 path uses, so the two stay bit-identical),
+// the epilogue is the fp8 engine's acc * (input scale x weight scale) + bias, SiLU, * 1 / out scale, e4m3 (8-byte stores); no residual form.
+template <typename GEO, bool RES, typename T = __bf16>
 __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 {
     using namespace g1;
     constexpr int NT = GEO::NT, TM = GEO::TM, TN = GEO::TN, ROWB = GEO::ROWB, STG = GEO::STG, NST = GEO::NST, NFJ = GEO::NFJ;
     constexpr int CH = GEO::CH, RPP = GEO::RPP, NPP = GEO::NPP, NPW = GEO::NPW, KSS = GEO::KSS, LEAD = GEO::LEAD;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr bool F8 = ESZ == 1;
+    static_assert(!F8 || (!RES && ROWB == 128), "fp8: 128-byte rows (one 16x16x128 instruction per row), no residual form");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const lbias = reinterpret_cast<float*>(smem + NST * STG);
+    float* const lmult = lbias + MAXC;                          // fp8: per-channel multipliers behind the biases
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int wm = wave / GEO::NWN, wn = wave % GEO::NWN;      // the wave's 64-pixel / NFJ * 16-channel part of the tile
-    const int kshift = ROWB == 64 ? 5 : 6;
+    const int kshift = (ROWB == 64 ? 5 : 6) + (F8 ? 1 : 0);   // log2 of the channels per step
     const int nk = a.Cin >> kshift;                            // steps per tile
     const bool dual = a.in2 != nullptr;
     const int k2 = dual ? a.in2_cin >> kshift : 0;             // steps of K that come from in2
     const int gy = a.Cout / TN;
     const int mtiles = (a.M + TM - 1) / TM;
     const int nitems = mtiles * gy;
-    const int wpitch = a.Kpad * 2;
+    const int wpitch = a.Kpad * ESZ;
 
     // workgroups that share an XCD (blockIdx % 8) take neighbouring items: the N tiles of one pixel tile meet in that XCD's L2
     const int G = gridDim.x;
@@ -123,6 +130,8 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
     const int total = my_items * nk;
 
     for (int i = tid; i < a.Cout; i += NT) lbias[i] = a.bias[i];
+    if (F8)
+        for (int i = tid; i < a.Cout; i += NT) lmult[i] = a.mult ? a.mult[i] : 1.0f;
 
     const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t irsrc2 =
@@ -152,7 +161,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
             const int m = mt * TM + row;
             const int cb = (dslot ^ swz<ROWB>(row & 15)) * 16;
             const bool ok = m < a.M;
-            vp[pp] = ok ? m * a.ldi * 2 + cb : -1;
+            vp[pp] = ok ? m * a.ldi * ESZ + cb : -1;
             vp2[pp] = -1;
             if (dual && ok) {
                 int m2 = m;
@@ -163,7 +172,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
                     const int b = q / a.Ho;
                     m2 = (b * (a.Ho >> 1) + (y >> 1)) * (a.Wo >> 1) + (x >> 1);
                 }
-                vp2[pp] = m2 * a.ldi2 * 2 + cb;
+                vp2[pp] = m2 * a.ldi2 * ESZ + cb;
             }
         }
     };
@@ -205,12 +214,12 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
     __syncthreads();                                           // bias visible (drains the first pieces too: once)
 
     int c_item = L, c_k = 0;
-    // the accumulators of an item start from the bias of ITS N tile (k_conv_halo.hip: acc_start explains; this kernel is bf16 only)
+    // bf16: the accumulators of an item start from the bias of ITS N tile (k_conv_halo.hip: acc_start explains); fp8: from zero
     auto acc_bias = [&](int item) {
         const int nb0 = (item % gy) * TN + wn * (NFJ * 16) + fq * 8;
 #pragma unroll
         for (int j = 0; j < NFJ; ++j) {
-            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(lbias + nb0 + (j >> 1) * 32 + (j & 1) * 4);
+            const f32x4_t b = F8 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4_t*>(lbias + nb0 + (j >> 1) * 32 + (j & 1) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = b;
         }
@@ -237,6 +246,32 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 #pragma unroll
             for (int sg = 0; sg < NFJ / 2; ++sg) rres[0][sg] = Out8<__bf16>::load(rrsrc, rb < 0 ? -1 : rb + sg * 64, 0);
         }
+        if constexpr (F8) {
+            // fp8: the two 64-byte halves of every 128-byte row in one 16x16x128 instruction; weight fragments in two halves of NFJ / 2 so that
+            // pixel + weight operands stay at 64 registers beside the 128 accumulator registers
+            u32x4_t pf0[4], pf1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf0[i] = *reinterpret_cast<const u32x4_t*>(sb + (pbase + i * (16 * ROWB)));
+                pf1[i] = *reinterpret_cast<const u32x4_t*>(sb + ((pbase + i * (16 * ROWB)) ^ 64));
+            }
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                u32x4_t wf0[NFJ / 2], wf1[NFJ / 2];
+#pragma unroll
+                for (int jj = 0; jj < NFJ / 2; ++jj) {
+                    const int j = jh * (NFJ / 2) + jj;
+                    wf0[jj] = *reinterpret_cast<const u32x4_t*>(sb + (wbase + j * (16 * ROWB)));
+                    wf1[jj] = *reinterpret_cast<const u32x4_t*>(sb + ((wbase + j * (16 * ROWB)) ^ 64));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jj = 0; jj < NFJ / 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fp8_mma128(wf0[jj], wf1[jj], pf0[i], pf1[i], acc[jh * (NFJ / 2) + jj][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KSS; ++ks) {
             // all fragment reads of a K-step go out before its first MFMA (counted lgkmcnt waits follow from the order): hipcc otherwise
@@ -258,6 +293,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         stage = stage == NST - 1 ? 0 : stage + 1;
         if (++c_k == nk) {
             // ---- epilogue: bias, activation, bf16, 16-byte channel vectors straight from registers ----
@@ -266,7 +302,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = mt * TM + wm * 64 + i * 16 + fr;
-                const int obase = m < a.M ? (m * a.ldo + n0 + fq * 8) * 2 : -1;
+                const int obase = m < a.M ? (m * a.ldo + n0 + fq * 8) * ESZ : -1;
                 if (RES && i < 3) {
                     const int rb = m + 16 < a.M ? ((m + 16) * a.ldr + n0 + fq * 8) * 2 : -1;
 #pragma unroll
@@ -275,21 +311,32 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 #pragma unroll
                 for (int sg = 0; sg < NFJ / 2; ++sg) {
                     float v[8];
+                    if constexpr (F8) {
+                        const int nl = n0 + sg * 32 + fq * 8;
+                        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(lbias + nl), b1 = *reinterpret_cast<const f32x4_t*>(lbias + nl + 4);
+                        const f32x4_t m0 = *reinterpret_cast<const f32x4_t*>(lmult + nl), m1 = *reinterpret_cast<const f32x4_t*>(lmult + nl + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {                  // (the bias was the accumulators' initial value)
-                        v[e] = acc[2 * sg][i][e];
-                        v[4 + e] = acc[2 * sg + 1][i][e];
+                        for (int e = 0; e < 4; ++e) {              // conv_stream_kernel's fp8 epilogue, operation by operation
+                            v[e] = acc[2 * sg][i][e] * m0[e] + b0[e];
+                            v[4 + e] = acc[2 * sg + 1][i][e] * m1[e] + b1[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {              // (the bias was the accumulators' initial value)
+                            v[e] = acc[2 * sg][i][e];
+                            v[4 + e] = acc[2 * sg + 1][i][e];
+                        }
                     }
                     if (a.act == ACT_SILU && !G1_OFF(4)) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = S1<__bf16>::silu(v[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = S1<T>::silu(v[e]);
                     } else if (a.act == ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     }
                     if (RES) Out8<__bf16>::add(rres[i & 1][sg], v, a.res_scale);
-                    const Out8<__bf16>::raw_t o = Out8<__bf16>::pack(v, 1.0f);
-                    Out8<__bf16>::store(o, orsrc, obase < 0 ? -1 : obase + sg * 64);      // (always issued: the waits count it)
+                    const typename Out8<T>::raw_t o = Out8<T>::pack(v, a.out_inv_scale);
+                    Out8<T>::store(o, orsrc, obase < 0 ? -1 : obase + sg * 32 * ESZ);      // (always issued: the waits count it)
                 }
             }
             c_k = 0;
@@ -320,14 +367,16 @@ static int g1_shape(const ConvArgs&) { return 2; }
 bool gemm1x1_ok(int dtype, const ConvArgs& a)
 {
     using namespace g1;
-    if (dtype != 1 || (a.out_dt >= 0 && a.out_dt != 1)) return false;
+    if ((dtype != 1 && dtype != 2) || (a.out_dt >= 0 && a.out_dt != dtype)) return false;
     if (a.ks != 1 || a.stride != 1 || a.head || a.up2 || a.src_mode || a.f2_w || a.c1_w || a.out_f32) return false;
-    const int shape = g1_shape(a);
-    const int tn = shape == 1 ? 128 : 256, kstep = shape == 0 ? 32 : 64;
+    const int shape = dtype == 2 ? 2 : g1_shape(a);
+    const int esz = dtype == 2 ? 1 : 2;
+    if (dtype == 2 && (a.res || a.ldi % 16 != 0 || (a.in2 && a.ldi2 % 16 != 0))) return false;      // fp8: 16-byte row pieces, no residual form
+    const int tn = shape == 1 ? 128 : 256, kstep = (shape == 0 ? 32 : 64) * (2 / esz);
     if (a.Cout % tn != 0 || a.Cout > MAXC || a.Cin % kstep != 0 || a.Cin < 3 * kstep || a.Kpad < a.Cin) return false;
     if (a.ldi % 8 != 0 || a.ldo % 8 != 0 || a.in_bytes == 0 || a.out_bytes == 0 || a.M <= 0) return false;
     if ((reinterpret_cast<size_t>(a.in) | reinterpret_cast<size_t>(a.out) | reinterpret_cast<size_t>(a.w)) & 15) return false;
-    if ((double)a.Cout * a.Kpad * 2 >= 2147483000.0) return false;
+    if ((double)a.Cout * a.Kpad * esz >= 2147483000.0) return false;
     if (a.res && (a.res_bytes == 0 || a.ldr % 8 != 0 || (reinterpret_cast<size_t>(a.res) & 15))) return false;
     if (a.in2) {
         if (a.in2_cin <= 0 || a.in2_cin >= a.Cin || a.in2_cin % kstep != 0 || a.in2_bytes == 0 || a.ldi2 % 8 != 0) return false;
@@ -343,9 +392,10 @@ bool gemm1x1_ok(int dtype, const ConvArgs& a)
     return shape == 2 && (a.Cin >= 512 || a.Cout >= 768) && a.Cin >= 256 && a.Cout >= 512 && 2 * items >= n_cu;
 }
 
-template <typename GEO, bool RES = false>
+template <typename GEO, bool RES = false, typename T = __bf16>
 static hipError_t g1_launch(const ConvArgs& a, hipStream_t s, int per_cu)
 {
+    constexpr size_t LDS = GEO::LDS_BYTES + (sizeof(T) == 1 ? g1::MAXC * 4 : 0);          // fp8: the multipliers behind the biases
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
     const long items = (long)((a.M + GEO::TM - 1) / GEO::TM) * (a.Cout / GEO::TN);
     const long slots = (long)per_cu * n_cu;
@@ -353,10 +403,10 @@ static hipError_t g1_launch(const ConvArgs& a, hipStream_t s, int per_cu)
     if (gx >= 8) gx &= ~7;                                     // whole XCD rounds (the item order in the kernel)
     static size_t attr[16] = {0};
     {
-        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(gemm1x1_kernel<GEO, RES>), GEO::LDS_BYTES, a.device, attr);
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(gemm1x1_kernel<GEO, RES, T>), LDS, a.device, attr);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gemm1x1_kernel<GEO, RES>), dim3(gx), dim3(GEO::NT), GEO::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm1x1_kernel<GEO, RES, T>), dim3(gx), dim3(GEO::NT), LDS, s, a);
     return hipGetLastError();
 }
 
@@ -365,6 +415,7 @@ hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t s, int* vari
     if (!gemm1x1_ok(dtype, a)) return hipErrorNotSupported;
     const int shape = g1_shape(a);
     if (variant) *variant = 3256;
+    if (dtype == 2) return g1_launch<GeoC, false, fp8_t>(a, s, 1);
 #ifdef SKY_EXPERIMENTS
     if (shape == 0 && !a.res) return g1_launch<GeoA>(a, s, 2);
     if (shape == 1 && !a.res) return g1_launch<GeoB>(a, s, 2);

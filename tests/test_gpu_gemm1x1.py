@@ -31,10 +31,10 @@ def _clear():
     os.environ.pop("SKY_GEMM1X1", None)
 
 
-def _conv(cin, cout, act, x, gemm, force=True):
+def _conv(cin, cout, act, x, gemm, force=True, precision="bf16"):
     _env(gemm, force)
     try:
-        m = load_seeded(ConvolutionBlock(cin, cout, 1, 1, activation=act), 17).eval().set_precision("bf16")
+        m = load_seeded(ConvolutionBlock(cin, cout, 1, 1, activation=act), 17).eval().set_precision(precision)
         y = m(x)
         h = m._engine([x])
         info = [h.op_info(i) for i in range(h.stats()["launches"])]
@@ -56,6 +56,30 @@ def test_gemm1x1_equals_stream_kernel(cin, cout, shape, act):
     assert not any("gemm1x1" in t for t in info_s), info_s
     assert bool(torch.isfinite(y_g).all())
     assert torch.equal(y_g, y_s), f"{int((y_g != y_s).sum())} of {y_g.numel()} values differ"
+
+
+# fp8 (round 4): 128 channels per 128-byte row and step, one 16x16x128 block-scaled instruction per row pair -- the streaming kernel's own pairing
+# of K-steps (fp8_mma128) and its epilogue (acc * multiplier + bias, SiLU, 1 / out scale, e4m3), so the bytes are equal
+@pytest.mark.parametrize("cin,cout,shape,act", [
+    (512, 512, (2, 40, 40), True), (384, 256, (1, 13, 9), True), (1024, 512, (1, 20, 24), True), (768, 512, (2, 17, 23), False),
+    (512, 256, (2, 80, 80), True), (384, 1024, (1, 12, 20), True), (640, 256, (1, 128, 1), True)], ids=lambda v: str(v).replace(" ", ""))
+def test_fp8_gemm1x1_equals_stream_kernel(cin, cout, shape, act):
+    B, H, W = shape
+    x = torch.from_numpy(seeded_input("g1f8.%d.%d.%d.%d" % (cin, B, H, W), (B, cin, H, W), 5, -2.0, 2.0)).cuda()
+    y_g, info_g = _conv(cin, cout, act, x, True, precision="fp8")
+    y_s, info_s = _conv(cin, cout, act, x, False, precision="fp8")
+    assert any("gemm1x1" in t for t in info_g), info_g
+    assert not any("gemm1x1" in t for t in info_s), info_s
+    assert bool(torch.isfinite(y_g).all()) and float(y_g.abs().max()) > 0
+    assert torch.equal(y_g, y_s), f"{int((y_g != y_s).sum())} of {y_g.numel()} values differ"
+
+
+def test_fp8_gemm1x1_refuses_what_it_cannot_tile():
+    """K below three 128-channel steps or not a multiple of 128 stays on the streaming kernel even when forced."""
+    for cin in (256, 192, 320):
+        x = torch.from_numpy(seeded_input("g1f8.no.%d" % cin, (1, cin, 16, 16), 5, -2.0, 2.0)).cuda()
+        _, info = _conv(cin, 256, True, x, True, precision="fp8")
+        assert not any("gemm1x1" in t for t in info), info
 
 
 def test_gemm1x1_default_choice():
@@ -92,6 +116,55 @@ def test_neck_second_input_through_the_gemm(hw):
     assert not any("gemm1x1" in t for t in info_b)
     for x, y in zip(a, b):
         assert torch.equal(x, y), f"{int((x != y).sum())} of {x.numel()} values differ"
+
+
+@pytest.mark.parametrize("hw", [(40, 40), (20, 36)])
+def test_fp8_neck_second_input_through_the_gemm(hw):
+    B, (H5, W5) = 2, hw
+    feats = [torch.from_numpy(seeded_input("g1n8.p%d.%d.%d" % (i, H5, W5), (B, c, H5 * s, W5 * s), 3 + i, -2.0, 2.0)).cuda()
+             for i, (c, s) in enumerate([(256, 4), (512, 2), (1024, 1)])]
+
+    def neck(gemm):
+        _env(gemm, True)
+        try:
+            m = load_seeded(FeatureNeck([256, 512, 1024], width_multiple=1.0), 31).set_precision("fp8")
+            outs = m(feats)
+            h = m._engine(list(feats))
+            return outs, [h.op_info(i) for i in range(h.stats()["launches"])]
+        finally:
+            _clear()
+
+    a, info_a = neck(True)
+    b, info_b = neck(False)
+    assert any(" in2" in t and "gemm1x1" in t for t in info_a), info_a
+    assert not any("gemm1x1" in t for t in info_b)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), f"{int((x != y).sum())} of {x.numel()} values differ"
+
+
+def test_fp8_detector_with_and_without_the_gemm():
+    """skyeye_l (BASELINE.json configs[4] / [5]'s model) in fp8, the GEMM forced onto every 1x1 layer it can tile (its default choice needs the
+    benchmark's pixel counts): same detections, bit for bit, also through the neck's in-place concat (the calibration twin materialises it)."""
+    P = detector_params("skyeye_l")
+    x = torch.from_numpy(seeded_scene(3, 256, 320, 43)).cuda()
+
+    def run(gemm):
+        _env(gemm, True)
+        try:
+            m = build_detector(variant_cfg("skyeye_l"))
+            m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()}, strict=True)
+            m = m.eval().set_precision("fp8")
+            d, raw = m(x)
+            h = m._engine([m._prepare_input(x)])
+            return d, raw, [h.op_info(i) for i in range(h.stats()["launches"])]
+        finally:
+            _clear()
+
+    d0, r0, i0 = run(True)
+    d1, r1, i1 = run(False)
+    assert sum("gemm1x1" in t for t in i0) >= 4 and any(" in2" in t and "gemm1x1" in t for t in i0), i0
+    assert not any("gemm1x1" in t for t in i1) and any(" in2" in t for t in i1), i1
+    assert torch.equal(d0, d1) and all(torch.equal(p, q) for p, q in zip(r0, r1))
 
 
 @pytest.mark.parametrize("variant,shape", [("skyeye_s", (2, 320, 320)), ("skyeye_s", (1, 1280, 1280)), ("skyeye_l", (2, 128, 96)), ("skyeye_s", (3, 96, 160)),

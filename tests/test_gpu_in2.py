@@ -62,3 +62,55 @@ def test_detector_with_and_without_the_materialised_concat():
         d0, r0 = run(True, x)
         d1, r1 = run(False, x)
         assert torch.equal(d0, d1) and all(torch.equal(p, q) for p, q in zip(r0, r1))
+
+
+# fp8 (round 4): one multiplier per output channel covers both parts of K because the small map carries the concat buffer's scale (tied); the
+# calibration twin writes the concat anyway, so both plans measure the same ranges and the bytes are equal
+@pytest.mark.parametrize("hw", [(20, 20), (12, 28), (10, 18)])
+def test_fp8_neck_reads_the_small_lateral_map(hw):
+    B, (H5, W5) = 2, hw
+    feats = [torch.from_numpy(seeded_input("in2f8.p%d.%d.%d" % (i, H5, W5), (B, c, H5 * s, W5 * s), 3 + i, -2.0, 2.0)).cuda()
+             for i, (c, s) in enumerate([(256, 4), (512, 2), (1024, 1)])]
+
+    def neck(small):
+        if not small:
+            os.environ["SKY_NO_IN2"] = "1"
+        try:
+            m = load_seeded(FeatureNeck([256, 512, 1024], width_multiple=1.0), 31).set_precision("fp8")
+            outs = m(feats)
+            h = m._engine(list(feats))
+            return outs, [h.op_info(i) for i in range(h.stats()["launches"])], h.scales()
+        finally:
+            os.environ.pop("SKY_NO_IN2", None)
+
+    a, info_a, sc_a = neck(True)
+    b, info_b, sc_b = neck(False)
+    assert sum(" in2" in t for t in info_a) == 2, info_a
+    assert not any(" in2" in t for t in info_b) and sum(" up2" in t for t in info_b) == 2
+    for x, y in zip(a, b):
+        assert bool(torch.isfinite(x.float()).all()) and torch.equal(x, y), f"{int((x != y).sum())} of {x.numel()} values differ"
+
+
+def test_fp8_detector_with_and_without_the_materialised_concat():
+    """skyeye_l (256 / 512 / 1024-channel levels: lateral maps of whole 256-byte slabs; skyeye_s's 64 / 128 bytes stay materialised)."""
+    P = detector_params("skyeye_l")
+
+    def run(small, x):
+        if not small:
+            os.environ["SKY_NO_IN2"] = "1"
+        try:
+            m = build_detector(variant_cfg("skyeye_l"))
+            m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()}, strict=True)
+            m = m.eval().set_precision("fp8")
+            d, raw = m(x)
+            h = m._engine([m._prepare_input(x)])
+            return d, raw, sum(" in2" in h.op_info(i) for i in range(h.stats()["launches"]))
+        finally:
+            os.environ.pop("SKY_NO_IN2", None)
+
+    for B, H, W in ((2, 320, 320), (1, 640, 384)):
+        x = torch.from_numpy(seeded_scene(B, H, W, 41)).cuda()
+        d0, r0, n0 = run(True, x)
+        d1, r1, n1 = run(False, x)
+        assert (n0, n1) == (2, 0)
+        assert torch.equal(d0, d1) and all(torch.equal(p, q) for p, q in zip(r0, r1))
