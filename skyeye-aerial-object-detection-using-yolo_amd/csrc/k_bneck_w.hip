@@ -23,7 +23,8 @@
 
 // compile-time experiment bits (tools/bneckw_ab.sh; the shipped value is the default below): 1 s_setprio 1 over the tap steps,
 // 2 counted wait at the head of a tile (the epilogue's 16 stores stay in flight), 4 the next tile's x chunk 0 requested behind the taps
-// of chunk 0
+// of chunk 0.  TIMING-ONLY bits (wrong results; what a wait costs): 8 the weight slabs are requested for the first tile only, 16 no s_barrier at the
+// head of a tap step (the waits stay)
 #ifndef BW_V
 #define BW_V 0
 #endif
@@ -293,9 +294,12 @@ __global__ void __launch_bounds__(bw::NT, 2) bneck128w_kernel(const ConvArgs a)
 #pragma unroll
         for (int s = NCH; s < NSTEP; ++s) {
             const int p = s & 1;
-            bw_wait_barrier();                                // slab s has landed everywhere, step s - 1 is over everywhere (s = 2: u is complete)
-            if (s + 1 < NSTEP) issue_slab(s + 1);
-            else if (has_next) issue_slab(0);
+            if ((BW_V & 16) && s > NCH) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else bw_wait_barrier();                           // slab s has landed everywhere, step s - 1 is over everywhere (s = 2: u is complete)
+            if (!(BW_V & 8) || first) {
+                if (s + 1 < NSTEP) issue_slab(s + 1);
+                else if (has_next) issue_slab(0);
+            }
             if ((BW_V & 4) && s == NCH + 9 && has_next) issue_x(nb, ny0, nx0, 1);      // chunk 0 of u is dead behind this barrier
             u32x4_t pf1[4], wq[4][2];                         // K-step 1 pixels; weight pairs of the four (K-step, channel pair) groups
             if (s == NCH) {
