@@ -97,13 +97,14 @@ __device__ __forceinline__ void g1_wait(int younger, bool st)
 // T = __bf16, or fp8_t (round 4; config 5's engine): the same 128-byte rows hold 128 channels, both 64-byte halves of a row go into ONE
 // 16x16x128 block-scaled instruction (fp8_mma128: the pairing of K-steps conv_stream_kernel's fp8 path uses, so the two stay bit-identical),
 // the epilogue is the fp8 engine's acc * (input scale x weight scale) + bias, SiLU, * 1 / out scale, e4m3 (8-byte stores); no residual form.
-template <typename GEO, bool RES, typename T = __bf16>
+// TO = __bf16 with T = fp8_t: the fp8 engine's last neck convolutions (the maps the detection levels read stay bf16, engine.cpp: neck).
+template <typename GEO, bool RES, typename T = __bf16, typename TO = T>
 __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 {
     using namespace g1;
     constexpr int NT = GEO::NT, TM = GEO::TM, TN = GEO::TN, ROWB = GEO::ROWB, STG = GEO::STG, NST = GEO::NST, NFJ = GEO::NFJ;
     constexpr int CH = GEO::CH, RPP = GEO::RPP, NPP = GEO::NPP, NPW = GEO::NPW, KSS = GEO::KSS, LEAD = GEO::LEAD;
-    constexpr int ESZ = (int)sizeof(T);
+    constexpr int ESZ = (int)sizeof(T), OSZ = (int)sizeof(TO);
     constexpr bool F8 = ESZ == 1;
     static_assert(!F8 || (!RES && ROWB == 128), "fp8: 128-byte rows (one 16x16x128 instruction per row), no residual form");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = mt * TM + wm * 64 + i * 16 + fr;
-                const int obase = m < a.M ? (m * a.ldo + n0 + fq * 8) * ESZ : -1;
+                const int obase = m < a.M ? (m * a.ldo + n0 + fq * 8) * OSZ : -1;
                 if (RES && i < 3) {
                     const int rb = m + 16 < a.M ? ((m + 16) * a.ldr + n0 + fq * 8) * 2 : -1;
 #pragma unroll
@@ -335,8 +336,8 @@ __global__ void __launch_bounds__(GEO::NT, 2) gemm1x1_kernel(const ConvArgs a)
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     }
                     if (RES) Out8<__bf16>::add(rres[i & 1][sg], v, a.res_scale);
-                    const typename Out8<T>::raw_t o = Out8<T>::pack(v, a.out_inv_scale);
-                    Out8<T>::store(o, orsrc, obase < 0 ? -1 : obase + sg * 32 * ESZ);      // (always issued: the waits count it)
+                    const typename Out8<TO>::raw_t o = Out8<TO>::pack(v, a.out_inv_scale);
+                    Out8<TO>::store(o, orsrc, obase < 0 ? -1 : obase + sg * 32 * OSZ);      // (always issued: the waits count it)
                 }
             }
             c_k = 0;
@@ -367,7 +368,7 @@ static int g1_shape(const ConvArgs&) { return 2; }
 bool gemm1x1_ok(int dtype, const ConvArgs& a)
 {
     using namespace g1;
-    if ((dtype != 1 && dtype != 2) || (a.out_dt >= 0 && a.out_dt != dtype)) return false;
+    if ((dtype != 1 && dtype != 2) || (a.out_dt >= 0 && a.out_dt != dtype && !(dtype == 2 && a.out_dt == 1))) return false;
     if (a.ks != 1 || a.stride != 1 || a.head || a.up2 || a.src_mode || a.f2_w || a.c1_w || a.out_f32) return false;
     const int shape = dtype == 2 ? 2 : g1_shape(a);
     const int esz = dtype == 2 ? 1 : 2;
@@ -392,7 +393,7 @@ bool gemm1x1_ok(int dtype, const ConvArgs& a)
     return shape == 2 && (a.Cin >= 512 || a.Cout >= 768) && a.Cin >= 256 && a.Cout >= 512 && 2 * items >= n_cu;
 }
 
-template <typename GEO, bool RES = false, typename T = __bf16>
+template <typename GEO, bool RES = false, typename T = __bf16, typename TO = T>
 static hipError_t g1_launch(const ConvArgs& a, hipStream_t s, int per_cu)
 {
     constexpr size_t LDS = GEO::LDS_BYTES + (sizeof(T) == 1 ? g1::MAXC * 4 : 0);          // fp8: the multipliers behind the biases
@@ -403,10 +404,10 @@ static hipError_t g1_launch(const ConvArgs& a, hipStream_t s, int per_cu)
     if (gx >= 8) gx &= ~7;                                     // whole XCD rounds (the item order in the kernel)
     static size_t attr[16] = {0};
     {
-        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(gemm1x1_kernel<GEO, RES, T>), LDS, a.device, attr);
+        const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(gemm1x1_kernel<GEO, RES, T, TO>), LDS, a.device, attr);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gemm1x1_kernel<GEO, RES, T>), dim3(gx), dim3(GEO::NT), LDS, s, a);
+    hipLaunchKernelGGL((gemm1x1_kernel<GEO, RES, T, TO>), dim3(gx), dim3(GEO::NT), LDS, s, a);
     return hipGetLastError();
 }
 
@@ -415,7 +416,7 @@ hipError_t launch_gemm1x1(int dtype, const ConvArgs& a, hipStream_t s, int* vari
     if (!gemm1x1_ok(dtype, a)) return hipErrorNotSupported;
     const int shape = g1_shape(a);
     if (variant) *variant = 3256;
-    if (dtype == 2) return g1_launch<GeoC, false, fp8_t>(a, s, 1);
+    if (dtype == 2) return a.out_dt == 1 ? g1_launch<GeoC, false, fp8_t, __bf16>(a, s, 1) : g1_launch<GeoC, false, fp8_t>(a, s, 1);
 #ifdef SKY_EXPERIMENTS
     if (shape == 0 && !a.res) return g1_launch<GeoA>(a, s, 2);
     if (shape == 1 && !a.res) return g1_launch<GeoB>(a, s, 2);
