@@ -80,6 +80,7 @@ struct Op {
     int wid = -1;          // index into Engine::convs
     int wid1 = -1;         // fused BottleneckBlock: packed weights of cv1 (the 1x1 computed on the halo tile of the 3x3, k_conv_halo.hip CV1)
     int c1_res = 0;        // ... with the shortcut x + cv2(cv1(x))
+    TV hid;                // ... fp8 plans: the hidden tensor cv1(x) as a SCALE CARRIER (a workspace buffer nobody allocates; the calibration twin writes the real one)
     int stem_down = 0;     // this FocusBlock convolution and the stride-2 convolution behind it can run as ONE kernel (k_stem_down.hip)
     int csp_stage = 0;     // cv1|cv2 of a CSPBlock whose whole stage (this op and the next three) can run as ONE kernel (k_csp_stage.hip)
     int csp_member = 0;    // one of those next three ops: skipped at run time when the stage kernel ran
@@ -489,17 +490,23 @@ static TV conv_block(Ctx& c, const std::string& p, const TV& x, int cin, int cou
 // would the halo-tile kernel run cv2(cv1(x)) of this bottleneck as ONE launch (conv_accepts_cv1)?
 static bool bottleneck_fusable(Ctx& c, const TV& x, int cin, int hidden, int cout)
 {
-    if (!c.emit || x.dt != SKY_BF16 || cin != hidden || hidden != cout) return false;
+    // the calibration twin of an fp8 plan answers for THAT plan (its tensors are all bf16; the plan's CSP tensors are fp8): the buffer lists must agree
+    const bool mirror = c.e.mirror_dtype >= 0;
+    const int dt = mirror ? c.e.mirror_dtype : (int)x.dt;
+    const unsigned opts = mirror ? c.e.mirror_opts : c.e.opts;
+    if (!c.emit || (dt != SKY_BF16 && dt != SKY_FP8) || cin != hidden || hidden != cout) return false;
+    if (!mirror && c.e.dtype == SKY_FP8 && x.dt != SKY_FP8) return false;       // (an fp8 plan fuses its fp8 tensors only)
+    const int esz = dtype_size(dt);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.B = x.B; a.H = x.H; a.W = x.W; a.Cin = hidden; a.ldi = x.ld; a.Ho = x.H; a.Wo = x.W; a.Cout = cout; a.ldo = x.ld;
     a.ks = 3; a.stride = 1; a.pad = 1; a.M = x.B * x.H * x.W; a.act = ACT_SILU;
-    a.Kpad = (9 * hidden + conv_k_step(SKY_BF16) - 1) / conv_k_step(SKY_BF16) * conv_k_step(SKY_BF16);
-    a.c1_Kpad = (cin + conv_k_step(SKY_BF16) - 1) / conv_k_step(SKY_BF16) * conv_k_step(SKY_BF16);
-    a.opts = c.e.opts; a.device = c.e.cfg.device; a.n_cu = c.e.n_cu; a.out_dt = SKY_BF16;
-    const double ext = ((double)a.M - 1.0) * x.ld * 2 + hidden * 2.0;
+    a.Kpad = (9 * hidden + conv_k_step(dt) - 1) / conv_k_step(dt) * conv_k_step(dt);
+    a.c1_Kpad = (cin + conv_k_step(dt) - 1) / conv_k_step(dt) * conv_k_step(dt);
+    a.opts = opts; a.device = c.e.cfg.device; a.n_cu = c.e.n_cu; a.out_dt = dt;
+    const double ext = ((double)a.M - 1.0) * x.ld * esz + hidden * (double)esz;
     a.in_bytes = a.out_bytes = ext < 2147483000.0 ? (unsigned)ext : 0u;
-    return conv_accepts_cv1(SKY_BF16, a);
+    return conv_accepts_cv1(dt, a);
 }
 
 // BottleneckBlock (blocks.py:69-90): x + cv2(cv1(x)) iff shortcut and cin == cout.  fused: one launch (cv1 on the halo tile of
@@ -515,7 +522,19 @@ static TV bottleneck(Ctx& c, const std::string& p, const TV& x, int cin, int cou
         need_bn(c, p + "cv2.bn.", cout);
         TV y = out_into ? *out_into : c.new_tensor(x.B, x.H, x.W, cout);
         if (y.buf == x.buf) throw Error(SKY_ERR_INVALID, p + ": a fused bottleneck cannot run in place");
+        if (c.e.mirror_dtype >= 0 || (c.e.opts & OPT_BNECK_PAIR)) {
+            // calibration twin of an fp8 plan (or SKY_BNECK128=pair): the same buffers in the same order (y, then the hidden tensor), written by the two-launch form
+            TV u = c.new_tensor(x.B, x.H, x.W, hidden);
+            ConvOpt o1;
+            o1.out_into = &u;
+            conv_block(c, p + "cv1.", x, cin, hidden, 1, 1, true, o1);
+            ConvOpt o2;
+            o2.out_into = &y;
+            if (shortcut && cin == cout) o2.res = &x;
+            return conv_block(c, p + "cv2.", u, hidden, cout, 3, 1, true, o2);
+        }
         Op op;
+        if (x.dt == SKY_FP8) op.hid = c.new_tensor(1, 1, 1, hidden);       // its scale is the hidden tensor's (sky_calibrate); never allocated, never written
         op.kind = OP_CONV;
         op.in = x; op.out = y;
         op.cin = hidden; op.cout = cout; op.ks = 3; op.stride = 1; op.act = ACT_SILU;
@@ -1544,6 +1563,11 @@ static void run(Engine& e, const sky_buffer* ins, int n_in, const sky_buffer* ou
                 if (op.wid1 >= 0) {
                     const DevConv& d1 = e.convs[op.wid1];
                     a.c1_w = d1.w; a.c1_bias = d1.bias; a.c1_Kpad = d1.Kpad; a.c1_res = op.c1_res;
+                    if (op.cdt == SKY_FP8) {
+                        a.c1_mult = d1.mult;
+                        a.c1_out_inv_scale = 1.0f / tv_scale(e, op.hid);
+                        a.res_scale = tv_scale(e, op.in);            // the shortcut is x itself
+                    }
                 }
                 if (op.head_op >= 0 && !amax && sl_nb < 0 && !a.f2_w && !a.src_mode) {
                     // CSP cv3 + the detection level that reads it: one kernel (k_head.hip), the level's op is skipped when it comes
@@ -1760,7 +1784,7 @@ static unsigned read_plan_opts()
     if (env("SKY_NO_CSP_STAGE")) o |= OPT_NO_CSP_STAGE;
     if (env("SKY_NO_HEAD_STREAM")) o |= OPT_NO_HEAD_STREAM;
     if (env("SKY_NO_BNECK128")) o |= OPT_NO_BNECK128;
-    if (const char* v = env("SKY_BNECK128")) o |= v[0] == 's' ? OPT_BNECK128_SOLO : 0u;
+    if (const char* v = env("SKY_BNECK128")) o |= v[0] == 's' ? OPT_BNECK128_SOLO : v[0] == 'p' ? OPT_BNECK_PAIR : 0u;
     if (env("SKY_NO_DEEP3X3")) o |= OPT_NO_DEEP3X3;
     if (env("SKY_NO_IN2")) o |= OPT_NO_IN2;
     if (env("SKY_NO_CV3_HEAD")) o |= OPT_NO_CV3_HEAD;
@@ -1850,10 +1874,17 @@ static void apply_scales(Engine& e)
     for (const Op& op : e.ops) {
         if (op.kind != OP_CONV || op.cdt != SKY_FP8) continue;
         DevConv& d = e.convs[op.wid];
-        const float si = tv_scale(e, op.in);
+        const float si = op.wid1 >= 0 ? tv_scale(e, op.hid) : tv_scale(e, op.in);      // fused bottleneck: the 3x3 reads the hidden tensor
         std::vector<float> m(d.rows);
         for (int r = 0; r < d.rows; ++r) m[r] = si * d.w_scale[r];
         SKY_HIP(hipMemcpy(d.mult, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (op.wid1 >= 0) {
+            DevConv& d1 = e.convs[op.wid1];
+            const float s1 = tv_scale(e, op.in);
+            std::vector<float> m1(d1.rows);
+            for (int r = 0; r < d1.rows; ++r) m1[r] = s1 * d1.w_scale[r];
+            SKY_HIP(hipMemcpy(d1.mult, m1.data(), m1.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
 }
 
@@ -2164,7 +2195,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? (op.in2_cin ? " +res in2" : " +res") : (op.in2_cin ? " in2" : ""), op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 3256 ? "gemm1x1/" : op.variant == 7128 ? "bneck" : op.variant == 7256 ? "bneck128x2/" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 3256 ? "gemm1x1/" : op.variant == 7128 ? "bneck" : op.variant == 7256 ? "bneck128x2/" : op.variant == 7257 ? "bneck128x2-fp8/" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)

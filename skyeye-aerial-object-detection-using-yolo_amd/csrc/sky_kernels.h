@@ -42,6 +42,7 @@ enum PlanOpt : unsigned {
     OPT_NO_GEMM1X1 = 1u << 27,       // SKY_NO_GEMM1X1       large-K 1x1 convolutions on the streaming kernel (default: the LDS-DMA GEMM, k_gemm1x1.hip)
     OPT_GEMM1X1_FORCE = 1u << 28,    // SKY_GEMM1X1=force    the GEMM wherever the shape is covered (default: K >= 256 and two tiles per CU or more)
     OPT_BNECK128_SOLO = 1u << 29,    // SKY_BNECK128=solo    128-channel bottlenecks on round 3's one-workgroup-per-CU kernel (default: two 4-wave workgroups per CU, k_bneck_w.hip)
+    OPT_BNECK_PAIR = 1u << 30,       // SKY_BNECK128=pair    fused bottlenecks keep their plan (buffers, scale carriers) but run as their two launches (tests: the fp8 identity needs equal scales)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -101,6 +102,9 @@ struct ConvArgs {
     const void* c1_w;    // T [Cin rows][c1_Kpad], BatchNorm folded, null = not fused
     const float* c1_bias;
     int c1_Kpad, c1_res;
+    // fp8 engine (k_bneck_w8.hip): u = e4m3(SiLU(acc * c1_mult[ch] + c1_bias[ch]) * c1_out_inv_scale); `mult` then holds hidden scale x weight scale
+    const float* c1_mult;
+    float c1_out_inv_scale;
     unsigned out_bytes, res_bytes;   // extents of the output / residual views in bytes (0 = 2 GiB or more)
     unsigned in_bytes;   // extent of the input view in bytes (buffer descriptor range; 0 = 2 GiB or more: not addressable with int32 offsets)
     // optional second input of a 1x1 convolution (streaming kernel): the first in2_cin channels of K come from `in2`, read with the
@@ -205,6 +209,9 @@ hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 bool bneck128_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck128(const ConvArgs& a, hipStream_t s);
 // the same block as two 4-wave workgroups per CU on 8 x 16 tiles (k_bneck_w.hip; round 4, the default)
+// the same bottleneck in the fp8 engine (k_bneck_w8.hip): 128 channels = one 128-byte chunk, 16x16x128 block-scaled instructions
+bool bneck128w8_shape_ok(const ConvArgs& a);
+hipError_t launch_bneck128w8(const ConvArgs& a, hipStream_t s);
 bool bneck128w_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck128w(const ConvArgs& a, hipStream_t s);
 

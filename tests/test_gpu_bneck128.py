@@ -68,3 +68,59 @@ def test_bneck128_against_fp32_engine():
     ref = load_seeded(M.CSPBlock(256, 256, num_blocks=3), 23).set_precision("fp32")(x)
     err = float((yf - ref).abs().max() / ref.abs().max())
     assert err < 0.03, err
+
+
+# ---- fp8 engine (round 4): k_bneck_w8.hip -- 128 channels are one 128-byte chunk, 16x16x128 block-scaled instructions -------------------------
+# The two-launch form it is compared with keeps the fused plan's buffers (SKY_BNECK128=pair: y1 -> A -> B -> y1 through the scratch tensors, the hidden
+# tensor materialised where the fused plan has its scale carrier), so both plans calibrate to the same scales; the in-place unfused plan
+# (SKY_NO_BNECK128=1) shares ONE scale between the stages of a CSP block and is only close.
+def _run8(n, x, mode, shortcut=True):
+    m = load_seeded(M.CSPBlock(256, 256, num_blocks=n, shortcut=shortcut), 23).set_precision("fp8")
+    if mode == "pair":
+        os.environ["SKY_BNECK128"] = "pair"
+    if mode == "inplace":
+        os.environ["SKY_NO_BNECK128"] = "1"
+    os.environ["SKY_CONV_HALO"] = "force"
+    try:
+        y = m(x)
+        h = m._engine([x])
+        info = [h.op_info(i) for i in range(h.stats()["launches"])]
+        scales = h.scales()
+    finally:
+        os.environ.pop("SKY_NO_BNECK128", None)
+        os.environ.pop("SKY_BNECK128", None)
+        os.environ.pop("SKY_CONV_HALO", None)
+    return y, info, scales
+
+
+CASES8 = [(3, 2, 48, 48), (2, 1, 16, 16), (2, 2, 40, 56), (4, 1, 33, 47), (3, 16, 96, 96), (3, 2, 24, 100)]
+
+
+@pytest.mark.parametrize("case", CASES8, ids=["n%d_b%d_%dx%d" % c for c in CASES8])
+def test_fp8_bneck128_equals_two_launch_form(case):
+    n, B, H, W = case
+    x = torch.from_numpy(seeded_input("bk128f8.x.%d.%d" % (H, W), (B, 256, H, W), 3, -2.0, 2.0)).cuda()
+    yf, info_f, sc_f = _run8(n, x, "fused")
+    yp, info_p, sc_p = _run8(n, x, "pair")
+    assert sum("bneck128x2-fp8" in t for t in info_f) == n, info_f
+    assert not any("bneck128" in t for t in info_p) and len(info_p) == len(info_f) + n, info_p
+    assert len(sc_f) == len(sc_p) and all(a == b for a, b in zip(sc_f, sc_p)), "the two plans calibrated to different scales"
+    assert bool(torch.isfinite(yf).all()) and float(yf.abs().max()) > 0
+    assert torch.equal(yf, yp), f"{int((yf != yp).sum())} of {yf.numel()} values differ, max {float((yf - yp).abs().max())}"
+    yf2, _, _ = _run8(n, x, "fused")
+    assert torch.equal(yf, yf2)
+
+
+def test_fp8_bneck128_without_shortcut_and_against_the_in_place_plan():
+    x = torch.from_numpy(seeded_input("bk128f8.ns", (2, 256, 40, 40), 7, -2.0, 2.0)).cuda()
+    yf, info_f, _ = _run8(2, x, "fused", shortcut=False)
+    yp, _, _ = _run8(2, x, "pair", shortcut=False)
+    assert sum("bneck128x2-fp8" in t for t in info_f) == 2 and torch.equal(yf, yp)
+    # the in-place plan (one scale for all stages of the block) is another quantisation of the same network: close, not equal
+    yf3, _, _ = _run8(3, x, "fused")
+    yi, info_i, _ = _run8(3, x, "inplace")
+    assert not any("bneck128" in t for t in info_i)
+    ref = load_seeded(M.CSPBlock(256, 256, num_blocks=3), 23).set_precision("fp32")(x)
+    ef = float((yf3.float() - ref).norm() / ref.norm()), float((yi.float() - ref).norm() / ref.norm())
+    print("fp8 CSP(256, n=3) relative L2 against fp32: fused plan %.4f, in-place plan %.4f" % ef)
+    assert ef[0] < 0.12 and ef[1] < 0.12, ef
