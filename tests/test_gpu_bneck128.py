@@ -78,6 +78,8 @@ def _run8(n, x, mode, shortcut=True):
     m = load_seeded(M.CSPBlock(256, 256, num_blocks=n, shortcut=shortcut), 23).set_precision("fp8")
     if mode == "pair":
         os.environ["SKY_BNECK128"] = "pair"
+    if mode == "big":                             # the 16 x 16-tile form of the kernel (measured slower, kept as a switch)
+        os.environ["SKY_BNECK128"] = "solo"
     if mode == "inplace":
         os.environ["SKY_NO_BNECK128"] = "1"
     os.environ["SKY_CONV_HALO"] = "force"
@@ -109,6 +111,8 @@ def test_fp8_bneck128_equals_two_launch_form(case):
     assert torch.equal(yf, yp), f"{int((yf != yp).sum())} of {yf.numel()} values differ, max {float((yf - yp).abs().max())}"
     yf2, _, _ = _run8(n, x, "fused")
     assert torch.equal(yf, yf2)
+    yb, info_b, _ = _run8(n, x, "big")
+    assert sum("bneck128x2-fp8" in t for t in info_b) == n and torch.equal(yb, yp)
 
 
 def test_fp8_bneck128_without_shortcut_and_against_the_in_place_plan():
