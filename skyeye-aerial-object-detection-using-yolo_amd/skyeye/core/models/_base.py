@@ -27,7 +27,7 @@ _EPOCH = [0]
 # toggles one between two calls of the same module gets a plan made under the new value
 _PLAN_SWITCHES = ("SKY_CONV_HALO", "SKY_HALO_NF8", "SKY_HALO_S2", "SKY_NO_STREAM", "SKY_NO_RING", "SKY_STREAM_OLDGRID",
                   "SKY_NO_FUSED_IMPORT", "SKY_FUSE", "SKY_NO_FUSE", "SKY_NO_SPP_PYRAMID", "SKY_ATTN_VALU", "SKY_HALO_SKIP",
-                  "SKY_NO_FUSE_CV1", "SKY_NO_STEM_DOWN", "SKY_SUBBATCH", "SKY_NO_WINATTN", "SKY_NO_CSP_STAGE", "SKY_NO_HEAD_STREAM", "SKY_HEAD_STREAM", "SKY_NO_BNECK128", "SKY_BNECK128", "SKY_NO_DEEP3X3", "SKY_NO_IN2", "SKY_NO_CV3_HEAD", "SKY_NO_GEMM1X1", "SKY_GEMM1X1")
+                  "SKY_NO_FUSE_CV1", "SKY_NO_STEM_DOWN", "SKY_SUBBATCH", "SKY_NO_WINATTN", "SKY_NO_CSP_STAGE", "SKY_NO_HEAD_STREAM", "SKY_HEAD_STREAM", "SKY_NO_BNECK128", "SKY_BNECK128", "SKY_NO_BNECK64W", "SKY_NO_DEEP3X3", "SKY_NO_IN2", "SKY_NO_CV3_HEAD", "SKY_NO_GEMM1X1", "SKY_GEMM1X1")
 
 
 def _bump_epoch():
