@@ -121,8 +121,8 @@ FAMILIES = [  # (name, kernel, predicate on the convolution variant tag recorded
     ("deep3x3", "conv3x3_deep_kernel: 3x3 stride 1, Cin >= 256: two halo images, 4-stage weight ring, counted waits", lambda v: 4600 <= v < 4800),
     ("halo3x3", "conv_halo_kernel: 3x3 halo tile + weight ring (stride 1 and 2)", lambda v: 4000 <= v < 5000 or 6000 <= v < 7000),
     ("halo_narrow", "conv_halo_small_kernel: stem / narrow-input 3x3, K resident", lambda v: 5000 <= v < 6000),
-    ("bneck128", "bneck128_kernel: BottleneckBlock(128, 128) 1x1 -> 3x3 (+residual) in one kernel, 4-stage weight ring", lambda v: v in (7128, 7256)),
-    ("halo_cv1", "conv_halo_kernel<CV1>: bottleneck 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
+    ("bneck128", "bneck128w_kernel (bf16) / bneck128w8_kernel (fp8): BottleneckBlock(128, 128) 1x1 -> 3x3 (+residual) in one kernel, two workgroups per CU", lambda v: v in (7128, 7256, 7257)),
+    ("halo_cv1", "bneck64w_kernel (three workgroups per CU) / conv_halo_kernel<CV1>: BottleneckBlock(64, 64) 1x1 -> 3x3 (+residual) fused", lambda v: 7000 <= v < 8000),
     ("stem_down", "stem_down_kernel: frames -> FocusBlock 3x3 -> 3x3 stride 2 in one kernel", lambda v: 8000 <= v < 8500),
     ("csp_stage", "csp_stage_kernel: CSPBlock(64, 64, 1) = cv1|cv2 -> 1x1 -> 3x3 + shortcut -> cv3 in one kernel", lambda v: 8500 <= v < 9000),
     ("stream_resident", "conv_stream_kernel: 1x1 (and narrow 3x3), weights resident in LDS", lambda v: 2000 <= v < 3000),

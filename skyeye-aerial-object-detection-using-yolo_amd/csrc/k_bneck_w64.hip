@@ -1,8 +1,9 @@
-// BottleneckBlock(64, 64) of the bf16 engine as ONE kernel with FOUR workgroups per CU: x + cv2_3x3(cv1_1x1(x))      reference blocks.py:69-90
+// BottleneckBlock(64, 64) of the bf16 engine as ONE kernel with THREE workgroups per CU: x + cv2_3x3(cv1_1x1(x))      reference blocks.py:69-90
 //
 // The halo-tile kernel's fused form (conv_halo_kernel<.., CV1>: a 16 x 16 tile, 62 KB of LDS, two workgroups per CU) in k_bneck_w8.hip's geometry
-// -- 64 bf16 channels are ONE 128-byte chunk -- with 8 x 16 tiles and 40 448 bytes of LDS: four 4-wave workgroups share a CU (four waves per SIMD),
-// each in another phase of its tile (x / W1 landing, cv1, taps, epilogue), so the waits of one are filled by three others instead of one:
+// -- 64 bf16 channels are ONE 128-byte chunk -- with 8 x 16 tiles and 40 448 bytes of LDS: three 4-wave workgroups share a CU (three waves per SIMD),
+// each in another phase of its tile (x / W1 landing, cv1, taps, epilogue), so the waits of one are filled by two others instead of one.  (Four fit
+// -- BW64_WG -- and measure the same, 0.0965 against 0.0974 ms; their 128-register budget spills five registers, 135 are used at three.)
 //   * x tile: 10 x 18 halo pixels x 128 bytes in the halo kernels' layout [K-group plane f][pixel slot, 184][2 x 16 B] = 23 552 bytes;
 //   * cv1: ONE slab W1 [64 rows][128 B] (step 0), u = SiLU(W1 x + b1) on the 12 pixel fragments of the halo tile (three per wave, all 64
 //     channels), written back over x IN PLACE (zeros outside the image); the residual vectors of a wave's own output pixels are read first;
@@ -34,7 +35,7 @@ constexpr int LDS_BYTES = TILE_BYTES + NST * SLAB + 2 * C * 4;
 #define BW64_V 0                                              // compile-time experiment bits: 1 the next tap's pixel fragments requested a step ahead (+32 registers)
 #endif
 #ifndef BW64_WG
-#define BW64_WG 4                                             // workgroups per CU the kernel is compiled for (register budget 512 / (BW64_WG) per lane)
+#define BW64_WG 3                                             // workgroups per CU the kernel is compiled for (register budget 512 / BW64_WG per lane)
 #endif
 static_assert(NFR == 3 * NW, "three halo fragments per wave");
 static_assert(BW64_WG * LDS_BYTES <= 160 * 1024, "workgroups per CU");

@@ -1216,7 +1216,7 @@ static bool cv1_shape_ok(int dtype, ConvArgs& a)
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2 || a.src_mode || a.f2_w) return false;
     if (a.Cin == 128 && a.Cout == 128) return bneck128w_shape_ok(a) || bneck128_shape_ok(a);      // the 128-channel bottleneck kernels (k_bneck_w.hip, k_bneck.hip)
     if (a.Cin != 64 || a.Cout != 64 || a.c1_Kpad < 64) return false;
-    if (bneck64w_shape_ok(a)) return true;                   // four workgroups per CU on 8 x 16 tiles (k_bneck_w64.hip)
+    if (bneck64w_shape_ok(a)) return true;                   // three workgroups per CU on 8 x 16 tiles (k_bneck_w64.hip)
     if (a.in_bytes == 0 || a.out_bytes == 0) return false;
     if ((long)a.Kpad * 2 < 9L * 128 || (a.opts & (OPT_HALO_OFF | OPT_NO_FUSE_CV1))) return false;
     const double cover = pick_tile(a, HPIX);

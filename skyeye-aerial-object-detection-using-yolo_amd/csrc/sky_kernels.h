@@ -43,7 +43,7 @@ enum PlanOpt : unsigned {
     OPT_GEMM1X1_FORCE = 1u << 28,    // SKY_GEMM1X1=force    the GEMM wherever the shape is covered (default: K >= 256 and two tiles per CU or more)
     OPT_BNECK128_SOLO = 1u << 29,    // SKY_BNECK128=solo    128-channel bottlenecks on round 3's one-workgroup-per-CU kernel (default: two 4-wave workgroups per CU, k_bneck_w.hip)
     OPT_BNECK_PAIR = 1u << 30,       // SKY_BNECK128=pair    fused bottlenecks keep their plan (buffers, scale carriers) but run as their two launches (tests: the fp8 identity needs equal scales)
-    OPT_NO_BNECK64W = 1u << 31,      // SKY_NO_BNECK64W      64-channel bottlenecks on the halo-tile kernel's fused form (default: four 4-wave workgroups per CU, k_bneck_w64.hip)
+    OPT_NO_BNECK64W = 1u << 31,      // SKY_NO_BNECK64W      64-channel bottlenecks on the halo-tile kernel's fused form (default: three 4-wave workgroups per CU, k_bneck_w64.hip)
     OPT_SKIP_SHIFT = 16,             // SKY_HALO_SKIP=<bits> bisection: bit 0 stride-1, 1 stride-2, 2 narrow, 3 128-ch, 4 64-ch tiles
 };
 
@@ -210,7 +210,7 @@ hipError_t launch_head_stream(int dtype, const ConvArgs& a, hipStream_t s, int* 
 bool bneck128_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck128(const ConvArgs& a, hipStream_t s);
 // the same block as two 4-wave workgroups per CU on 8 x 16 tiles (k_bneck_w.hip; round 4, the default)
-// BottleneckBlock(64, 64), bf16, 8 x 16 tiles, four workgroups per CU (k_bneck_w64.hip)
+// BottleneckBlock(64, 64), bf16, 8 x 16 tiles, three workgroups per CU (k_bneck_w64.hip)
 bool bneck64w_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck64w(const ConvArgs& a, hipStream_t s);
 // the same bottleneck in the fp8 engine (k_bneck_w8.hip): 128 channels = one 128-byte chunk, 16x16x128 block-scaled instructions

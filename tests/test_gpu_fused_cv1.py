@@ -1,4 +1,4 @@
-"""The fused BottleneckBlock(64, 64) launch -- round 4's four 4-wave workgroups per CU on 8 x 16 tiles (k_bneck_w64.hip, the default) and the halo-tile
+"""The fused BottleneckBlock(64, 64) launch -- round 4's three 4-wave workgroups per CU on 8 x 16 tiles (k_bneck_w64.hip, the default) and the halo-tile
 kernel's form (k_conv_halo.hip CV1, SKY_NO_BNECK64W=1: cv1 computed on the 18 x 18 halo tile of the 3x3, residual from the LDS tile): both
 bit-identical to the two-launch form (SKY_NO_FUSE_CV1=1) -- same MFMA instructions in the same order, same bf16 roundings --
 on CSP blocks with 2, 3 and 4 bottlenecks, ragged maps (image borders inside tiles, non-square tile shapes) and B = 16 at the
@@ -50,7 +50,7 @@ def test_fused_bottlenecks_equal_two_launch_form(case):
     yf2, _ = _run(n, x, True, halo=True)
     assert torch.equal(yf, yf2)
     yw, info_w = _run(n, x, True, force=True)                              # the default: k_bneck_w64.hip
-    assert sum("bneck64x4" in t for t in info_w) == n, info_w
+    assert sum("bneck64x3" in t for t in info_w) == n, info_w
     assert torch.equal(yw, yu), f"{int((yw != yu).sum())} of {yw.numel()} values differ, max {float((yw - yu).abs().max())}"
     yw2, _ = _run(n, x, True, force=True)
     assert torch.equal(yw, yw2)
@@ -71,7 +71,7 @@ def test_bneck64w_without_shortcut_and_single_tiles():
                 for k in env:
                     os.environ.pop(k, None)
             if "SKY_CONV_HALO" in env:
-                assert sum("bneck64x4" in t for t in info) == 2, info
+                assert sum("bneck64x3" in t for t in info) == 2, info
         assert torch.equal(outs[0], outs[1]), (B, H, W, sc)
 
 

@@ -19,6 +19,8 @@ def family(k):
         return "stem_down"
     if "csp_stage_kernel" in k:
         return "csp_stage"
+    if "bneck64w" in k:
+        return "halo_cv1"            # BottleneckBlock(64, 64) fused: k_bneck_w64.hip (default) or the halo-tile kernel's CV1 form
     if "bneck128" in k:
         return "bneck128"
     if "conv3x3_deep_kernel" in k:

@@ -32,6 +32,10 @@ for k, v in agg.items():
         variant = 8064
     elif "csp_stage_kernel" in k:
         variant = 8564
+    elif "bneck128w8" in k:
+        variant = 7257
+    elif "bneck64w" in k:
+        variant = 7065
     elif "bneck128w" in k:
         variant = 7256
     elif "bneck128" in k:
