@@ -116,6 +116,22 @@ __device__ __forceinline__ void fp8_mma128(const u32x4_t& w0, const u32x4_t& w1,
     acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
+// ---- XCD-aware tile order of a persistent tile kernel ------------------------------------------------------------------------
+// Workgroup b of a launch runs on XCD b % 8 (MI355X_MICROARCH.md), each with its own L2.  With tile = b, b + G, ... horizontally adjacent
+// tiles -- which share their halo columns and, for byte-granular frames, the cache lines their rows start and end in -- sit on eight different
+// XCDs, and every L2 fetches the shared lines again.  Here XCD x owns the CONTIGUOUS tile range [x n / 8, (x + 1) n / 8) and its G / 8
+// workgroups walk it side by side: neighbours meet in one L2.  Same tiles, same arithmetic; only who computes which tile changes.
+__device__ __forceinline__ void tile_walk(int ntile, int& first, int& step, int& end)
+{
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    if (G & 7) { first = b; step = G; end = ntile; return; }
+    const int x = b & 7;
+    const int lo = (int)(((long)x * ntile) >> 3);
+    end = (int)(((long)(x + 1) * ntile) >> 3);
+    step = G >> 3;
+    first = lo + (b >> 3);
+}
+
 // ---- 8 consecutive output channels of one pixel in the OUTPUT element type TO (epilogues of every convolution kernel) ----
 // raw_t: the bytes as loaded / stored; add(): residual += ; pack(): fp32 -> bytes (fp8: times 1 / out scale, saturated)
 template <typename TO> struct Out8;

@@ -112,8 +112,9 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
     const int hc = wave & 1, pg = wave >> 1;                  // channel half, pixel group (tile rows 4 pg .. 4 pg + 3)
     const int tiles_x = (a.W + TS - 1) / TS, tiles_y = (a.H + TS - 1) / TS;
     const int ntile = a.B * tiles_y * tiles_x;
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     const int pix_b = a.ldi * 2;
     const int w1pitch = a.c1_Kpad * 2, w2pitch = a.Kpad * 2;
 
@@ -198,8 +199,8 @@ __global__ void __launch_bounds__(bk::NT) bneck128_kernel(const ConvArgs a)
     bool first = true;
 
     for (;;) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntile;
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
         Out8<__bf16>::raw_t resv[4][2];                       // residual x of this lane's 4 x 2 output vectors
         BK_STAMP(0);
         u32x4_t wq01[2][2][2];                                // [step parity][channel pair][fragment]: weight pairs of K-step 0, requested a step ahead

@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(bw::NT, 2) bneck128w_kernel(const ConvArgs a)
     const int hc = wave & 1, pg = wave >> 1;                  // channel half, pixel group (tile rows 4 pg .. 4 pg + 3)
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntile = a.B * tiles_y * tiles_x;
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     const int pix_b = a.ldi * 2;
     const int w1pitch = a.c1_Kpad * 2, w2pitch = a.Kpad * 2;
 
@@ -157,8 +158,8 @@ __global__ void __launch_bounds__(bw::NT, 2) bneck128w_kernel(const ConvArgs a)
     bool first = true;
 
     for (;;) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntile;
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
         Out8<__bf16>::raw_t resv[4][2];                       // residual x of this lane's 4 x 2 output vectors
 
         // ---------------- steps 0, 1: cv1 on this wave's halo fragments wave, wave + 4, wave + 8 ----------------

@@ -68,8 +68,9 @@ __global__ void __launch_bounds__(bw64::NT, BW64_WG) bneck64w_kernel(const ConvA
     const int hc = wave & 1, pg = wave >> 1;                  // channel half (32 channels), pixel group (tile rows 4 pg .. 4 pg + 3)
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntile = a.B * tiles_y * tiles_x;
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     const int pix_b = a.ldi * 2;
     const int w1pitch = a.c1_Kpad * 2, w2pitch = a.Kpad * 2;
 
@@ -137,8 +138,8 @@ __global__ void __launch_bounds__(bw64::NT, BW64_WG) bneck64w_kernel(const ConvA
     issue_x(bimg, y0, x0);
 
     for (;;) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntile;
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
         Out8<__bf16>::raw_t resv[4];                          // residual x of this lane's 4 output vectors (8 channels each)
 
         // ---------------- step 0: cv1 on this wave's halo fragments wave, wave + 4, wave + 8 ----------------

@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(bw8::NT, 2) bneck128w8_kernel(const ConvArgs a
     const int hc = wave % G::NHC, pg = wave / G::NHC;         // channel part, pixel group (tile rows 4 pg .. 4 pg + 3)
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntile = a.B * tiles_y * tiles_x;
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     const int pix_b = a.ldi;
     const int w1pitch = a.c1_Kpad, w2pitch = a.Kpad;
 
@@ -153,8 +154,8 @@ __global__ void __launch_bounds__(bw8::NT, 2) bneck128w8_kernel(const ConvArgs a
     issue_x(bimg, y0, x0);
 
     for (;;) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntile;
+        const int next = tile + tstep;
+        const bool has_next = next < tend;
         constexpr bool RES_LDS = TH == 8;                     // 16 x 16 tiles: 32 more registers across the taps would spill; the epilogue reads x again (L2)
         Out8<fp8_t>::raw_t resv[4][NFJ / 2];                  // residual x of this lane's 4 x NFJ / 2 output vectors
 

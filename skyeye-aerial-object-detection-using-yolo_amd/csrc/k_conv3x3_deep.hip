@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(dp::NT) conv3x3_deep_kernel(const ConvArgs a)
     const int tiles_x = (a.W + TS - 1) / TS, tiles_y = (a.H + TS - 1) / TS;
     const int gy = a.Cout / NB;
     const int nitem = a.B * tiles_y * tiles_x * gy;
-    int item = blockIdx.x;
-    if (item >= nitem) return;
+    int item, tstep, tend;                                    // XCD-aware item order (conv_frag.h: tile_walk): the N tiles of a pixel tile stay neighbours
+    tile_walk(nitem, item, tstep, tend);
+    if (item >= tend) return;
     const int pix_b = a.ldi * 2;
     const int Cb = a.Cin * 2;                                 // bytes of one tap of K
     const int NG = (Cb >> 7) / GC;                            // passes of the unrolled body (Cin = 256: 1)
@@ -180,8 +181,8 @@ __global__ void __launch_bounds__(dp::NT) conv3x3_deep_kernel(const ConvArgs a)
 
     u32x4_t pf0[2][4], wq01[2][2][2];                         // [step parity]: K-step 0 pixel fragments / weight pairs, requested a step ahead
     for (;;) {
-        const int next = item + gridDim.x;
-        const bool has_next = next < nitem;
+        const int next = item + tstep;
+        const bool has_next = next < tend;
         int nb = 0, ny0 = 0, nx0 = 0, nn0 = 0;
         if (has_next) decode_item(next, nb, ny0, nx0, nn0);
         Out8<__bf16>::raw_t resv[4][2];

@@ -519,8 +519,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
     // ---- persistent tile loop (everything below is uniform per workgroup) ----
     // A tile is the linear sequence g = chunk * 9 + q of (halo phase, tap) steps; weight slab g + 1 is requested while
     // step g computes, a new halo tile (new chunk or, with S2, new parity phase) after a barrier at its first step.
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     int bimg, y0, x0;
     decode_tile(tile, bimg, y0, x0);
     const int G = nchunk * 9;
@@ -583,9 +584,9 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
         }
         // the next tile's first halo tile and weight slab are requested BEFORE this tile's epilogue: their latency runs
         // under the activation math and the stores
-        const int next = tile + gridDim.x;
+        const int next = tile + tstep;
         int nb = 0, ny0 = 0, nx0 = 0;
-        if (next < ntile) {
+        if (next < tend) {
             decode_tile(next, nb, ny0, nx0);
             __syncthreads();
             dbg_stamp(a, stamps, nth, 40);
@@ -603,7 +604,7 @@ __global__ void __launch_bounds__(HWV * 64, 2) __attribute__((amdgpu_num_vgpr(SK
             dbg_stamp(a, stamps, nth, 43);
         }
         ++nth;
-        if (next >= ntile) break;
+        if (next >= tend) break;
         tile = next; bimg = nb; y0 = ny0; x0 = nx0;
     }
     if ((SKY_DBG(a) & 256) && a.raw && nth >= 2 && threadIdx.x == 0 && blockIdx.y == 0) {
@@ -663,8 +664,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
     const int hpw = tile_w + 2, hpix = hpw * (tile_h + 2);
     const int ntile = a.B * tiles_y * tiles_x;
     const int pix_b = a.ldi * (int)sizeof(T);
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
 
     // ---- weights and bias: once per workgroup ----
     {
@@ -840,8 +842,8 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         wait_vmcnt0();                 // this wave's halo pieces have landed (and the previous tile's stores)
         __syncthreads();               // everybody's pieces have landed; everybody is done reading the other buffer (and lbias is visible)
         if constexpr (BiasInAcc<T>::value) acc_start<T, NF>(acc, lbias, fq);      // this tile's accumulators start from the bias
-        const int next = tile + gridDim.x;
-        if (next < ntile) issue_halo(next, (it + 1) & 1);      // SRC: the raw loads fly under the MFMAs; converted below
+        const int next = tile + tstep;
+        if (next < tend) issue_halo(next, (it + 1) & 1);      // SRC: the raw loads fly under the MFMAs; converted below
         const char* hb = hlds + (it & 1) * HB;
         if constexpr (sizeof(T) == 1) {
             // fp8: K-steps in pairs through the 16x16x128 instruction; an odd last K-step through the 16x16x32 pair
@@ -884,7 +886,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_kernel(const ConvArg
         if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        if (next >= ntile) break;
+        if (next >= tend) break;
         if (SRC) store_raw((it + 1) & 1);    // the other buffer: nobody reads it before the barrier at the loop top
         tile = next;
         ++it;
@@ -911,8 +913,9 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
     const int hpw = tile_w + 2, hpix = hpw * (tile_h + 2);
     const int ntile = a.B * tiles_y * tiles_x;
     const int pix_b = a.ldi * (int)sizeof(T);
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     {
         const char* wsrc = reinterpret_cast<const char*>(a.w);
         const long wpitch = (long)a.Kpad * (long)sizeof(T);
@@ -971,7 +974,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
     issue_halo(tile, 0, 0);
     int u = 0;                                    // (tile, phase) counter: halo buffer u & 1
     for (;;) {
-        const int next = tile + gridDim.x;
+        const int next = tile + tstep;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
             wait_vmcnt0();
@@ -980,7 +983,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
                 if (ph == 0) acc_start<T, NF>(acc, lbias, fq);   // this tile's accumulators start from the bias (lbias is visible behind the barrier)
             }
             if (ph < 3) issue_halo(tile, ph + 1, (u + 1) & 1);
-            else if (next < ntile) issue_halo(next, 0, (u + 1) & 1);
+            else if (next < tend) issue_halo(next, 0, (u + 1) & 1);
             const char* hb = hlds + (u & 1) * HB;
             constexpr int Q0[4] = {0, 4, 6, 8}, QN[4] = {4, 2, 2, 1};
 #pragma unroll
@@ -1008,7 +1011,7 @@ __global__ void __launch_bounds__(HWV * 64) conv_halo_small_s2_kernel(const Conv
         if (a.act == ACT_SILU) tile_epilogue<T, NF, ACT_SILU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else if (a.act == ACT_RELU) tile_epilogue<T, NF, ACT_RELU, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
         else tile_epilogue<T, NF, ACT_NONE, SQ, 0, TO>(a, acc, lbias, orsrc, rrsrc, bimg, y0, x0, wave * 64 + fr, n0 + fq * 8);
-        if (next >= ntile) break;
+        if (next >= tend) break;
         tile = next;
     }
 }

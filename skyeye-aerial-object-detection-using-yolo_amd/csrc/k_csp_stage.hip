@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_x = (a.W + TS - 1) / TS, tiles_y = (a.H + TS - 1) / TS;
     const int ntile = a.B * tiles_y * tiles_x;
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
     const int pix_b = a.ldi * 2;
 
     cs_stage_weights<C, 2>(a.w12, a.kpad12, w12, tid);
@@ -195,9 +196,9 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
             *reinterpret_cast<u32x4_t*>(y2t + fq * CPLN + (r * 16 + fr) * 16) = Out8<__bf16>::pack(v, 1.0f).a;
         }
         __syncthreads();                                          // u, y1, y2 complete; x is dead
-        const int next = tile + gridDim.x;
+        const int next = tile + tstep;
         int nb = 0, ny0 = 0, nx0 = 0;
-        if (next < ntile) {
+        if (next < tend) {
             decode_tile(next, nb, ny0, nx0);
             issue_x(nb, ny0, nx0);                                // flies under step 4
         }
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(cs::NT) csp_stage_kernel(const CspStageArgs a)
                 }
             }
         }
-        if (next >= ntile) break;
+        if (next >= tend) break;
         tile = next; bimg = nb; y0 = ny0; x0 = nx0;
     }
 }

@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
     const int Hs = a.Hr / 2, Ws = a.Wr / 2;                       // stem / space-to-depth map
     const int tiles_x = (a.Wo + TS - 1) / TS, tiles_y = (a.Ho + TS - 1) / TS;
     const int ntile = a.B * tiles_y * tiles_x;
-    int tile = blockIdx.x;
-    if (tile >= ntile) return;
+    int tile, tstep, tend;                                   // XCD-aware tile order (conv_frag.h: tile_walk)
+    tile_walk(ntile, tile, tstep, tend);
+    if (tile >= tend) return;
 
     sd_stage_weights<C1, KS1>(a.w1, a.kpad1, 9 * 32, w1, tid);
     sd_stage_weights<C2, 9>(a.w2, a.kpad2, 9 * 64, w2, tid);
@@ -216,8 +217,8 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
             }
         }
         __syncthreads();                                          // s2d tile complete; the raw block is dead, the stem tile may be written
-        const int next = tile + gridDim.x;
-        if (next < ntile) load_raw(next);                         // flies under phases B and C
+        const int next = tile + tstep;
+        if (next < tend) load_raw(next);                         // flies under phases B and C
 
         // ---- phase B: stem convolution on the 33 x 33 stem pixels: PFW fragments per wave in groups of three ----
         const f32x4_t bia0 = *reinterpret_cast<const f32x4_t*>(b1 + fq * 8);
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(sd::NT) stem_down_kernel(const StemDownArgs a)
                 }
             }
         }
-        if (next >= ntile) break;
+        if (next >= tend) break;
         tile = next;
         __syncthreads();                                          // everybody is done reading the stem tile (the next raw block goes there)
     }
