@@ -455,22 +455,38 @@ def main():
         prof = h.profile_forward([N.buffer_from_tensor(x)], [N.buffer_from_tensor(t) for t in outs], stream, iters=3)
         fam = {}
         last = "non_conv"
+        frames_rd, chain_out = None, 0.0
         # an interval between two hipEvents holds one event's own processing besides the launch: the ops that launch nothing (computed by an
         # earlier kernel) measure exactly that (~5 us); it is taken off every interval so that a family's average agrees with the kernel
         # durations rocprofv3 reports for the same launches (profiles/*_kernel_stats_streams1.csv; what stays is the launch gap of an eager run)
-        empty = [ms for ms, _fl, tag in prof if tag // 10000 == 2 and tag % 10000 >= 9000]
+        empty = [ms for ms, _fl, tag in prof if tag // 10000 in (0, 2) and tag % 10000 >= 9000]
         ev_over = min(empty) if empty else 0.0
         for i, (ms, fl, tag) in enumerate(prof):
-            folded = tag // 10000 == 2 and tag % 10000 >= 9000       # an op another launch computed: its FLOPs belong to that launch
+            folded = tag // 10000 in (0, 2) and tag % 10000 >= 9000  # an op another launch computed (a convolution, the skipped import): its FLOPs belong to that launch
+            rd, wr = h.op_io_bytes(i, with_raw=a.with_raw)
+            info = h.op_info(i).split()
+            if folded and info[0] == "import":
+                frames_rd = rd                                   # the import launches nothing: the stem reads the caller's frames itself
+                continue
             name = last if folded else family_of(tag)
+            if folded and "head" in info and "cv3_head" in fam:
+                name = "cv3_head"                                # the level the cv3 + level kernel computed (its op sits behind the neck's other launches)
             e = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, variants=set()))
             ms = 0.0 if folded else max(ms - ev_over, 0.0)
             e["ms"] += ms; e["flops"] += fl
             if not folded:
-                e["launches"] += 1; e["bytes"] += h.op_bytes(i)
+                if frames_rd is not None:
+                    rd, frames_rd = frames_rd, None              # (instead of the tensor the import would have written)
+                e["launches"] += 1; e["bytes"] += rd + wr
                 if tag // 10000 == 2:
                     e["variants"].add(tag % 10000)
                 last = name
+                chain_out = wr                                   # what this launch writes, until a folded op says its output stays on chip
+            elif "head" in info:
+                e["bytes"] += wr                                 # a detection level computed by the previous launch: its rows are written as well
+            else:
+                e["bytes"] += wr - chain_out                     # a folded convolution: the chain writes ITS output instead of the previous op's
+                chain_out = wr
         peak = PEAK_TFLOPS[a.precision]
         pmc, pmc_src, pmc_lib = {}, None, None
         if a.model == "skyeye_s" and B == 32 and S == 1280 and a.precision == "bf16":

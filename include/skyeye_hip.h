@@ -307,6 +307,12 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len);
 /* Algorithmic HBM bytes of launch `index` (activation input + output + residual views, in the engine's dtype). */
 int sky_op_bytes(const sky_handle* h, int index, double* bytes);
 
+/* The same, split into what the op reads (input, second input, residual) and what it writes (output map; a detection level: its decoded rows
+ * and -- `with_raw` != 0 -- its raw level).  A launch that computes a chain of planned ops (sky_op_info: "fused-into-previous") reads the
+ * first op's inputs and writes the last op's output (+ the outputs of the detection levels in the chain): profiling reports add those up
+ * (bench.py: roofline.families.algorithmic_bytes_per_launch). */
+int sky_op_io_bytes(const sky_handle* h, int index, int with_raw, double* read_bytes, double* written_bytes);
+
 #ifdef __cplusplus
 }
 #endif

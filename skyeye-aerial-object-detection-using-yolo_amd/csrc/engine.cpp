@@ -2183,7 +2183,7 @@ int sky_profile_forward(sky_handle* h, int n_inputs, const sky_buffer* inputs, i
             const Op& op = h->e.ops[i];
             if (ms_per_op) ms_per_op[i] = (float)(acc[i] / std::max(iters, 1));
             if (flops_per_op) flops_per_op[i] = op.flops;
-            if (tag_per_op) tag_per_op[i] = (int)op.kind * 10000 + (op.kind == OP_CONV ? op.variant : 0);
+            if (tag_per_op) tag_per_op[i] = (int)op.kind * 10000 + (op.kind == OP_CONV || op.kind == OP_IMPORT ? op.variant : 0);      // (import: 9100 = skipped, the stem reads the frames)
         }
     });
 }
@@ -2216,6 +2216,20 @@ int sky_op_bytes(const sky_handle* h, int index, double* bytes)
     if (op.kind == OP_CONV && op.head) b += 2.0 * op.in.B * op.Ho * op.Wo * (double)op.cout * 4;   // raw + decoded, fp32
     if (op.kind == OP_IMPORT) b += (double)op.out.B * op.src_c * op.src_h * op.src_w;                // uint8 frames (4x for fp32 input)
     *bytes = b;
+    return SKY_OK;
+}
+
+int sky_op_io_bytes(const sky_handle* h, int index, int with_raw, double* read_bytes, double* written_bytes)
+{
+    if (!h || !read_bytes || !written_bytes || index < 0 || index >= (int)h->e.ops.size()) return SKY_ERR_INVALID;
+    const Op& op = h->e.ops[index];
+    const int es = h->e.esize();
+    auto sz = [&](const TV& t, int esz) { return (t.buf >= 0 || t.ext >= 0) && t.B ? (double)t.B * t.H * t.W * t.C * (t.buf >= 0 ? dtype_size(t.dt) : esz) : 0.0; };
+    double r = sz(op.in, es) + sz(op.res, es) + sz(op.in2, es), w = sz(op.out, es);
+    if (op.kind == OP_CONV && op.head) w += (with_raw ? 2.0 : 1.0) * op.in.B * op.Ho * op.Wo * (double)op.cout * 4;   // decoded rows (+ raw level), fp32
+    if (op.kind == OP_IMPORT) r = (double)op.out.B * op.src_c * op.src_h * op.src_w;                 // the caller's frames as uint8 (4x for fp32 input)
+    *read_bytes = r;
+    *written_bytes = w;
     return SKY_OK;
 }
 

@@ -57,7 +57,7 @@ class SkyNmsParams(ctypes.Structure):
 # every symbol include/skyeye_hip.h declares (tests/test_abi.py checks the library exports all of them)
 SYMBOLS = ["sky_abi_version", "sky_build_info", "sky_device_count", "sky_last_error", "sky_create", "sky_destroy", "sky_num_params",
            "sky_param_info", "sky_load_weights", "sky_plan", "sky_num_outputs", "sky_output_info", "sky_forward", "sky_nms",
-           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_offset_boxes", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_packed_scales", "sky_calibrate", "sky_num_scales", "sky_scales_read", "sky_scales_write", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes"]
+           "sky_nms_fetch", "sky_box_iou", "sky_letterbox", "sky_scale_img", "sky_map_detections", "sky_offset_boxes", "sky_tile_gather", "sky_num_packed", "sky_packed_info", "sky_packed_read", "sky_packed_scales", "sky_calibrate", "sky_num_scales", "sky_scales_read", "sky_scales_write", "sky_plan_stats", "sky_time_forward", "sky_profile_forward", "sky_op_info", "sky_op_bytes", "sky_op_io_bytes"]
 
 _lib = None
 
@@ -105,6 +105,7 @@ def lib():
                                       ctypes.POINTER(ctypes.c_int32)]
     L.sky_op_info.argtypes = [vp, ip, ctypes.c_char_p, ip]
     L.sky_op_bytes.argtypes = [vp, ip, ctypes.POINTER(ctypes.c_double)]
+    L.sky_op_io_bytes.argtypes = [vp, ip, ip, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.sky_nms.argtypes = [vp, vp, ip, ip, ip, ctypes.POINTER(SkyNmsParams), vp, vp, vp]
     L.sky_nms_fetch.argtypes = [vp, vp, ip, vp, vp]
     L.sky_box_iou.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp]
@@ -300,6 +301,12 @@ class Handle:
         b = ctypes.c_double()
         check(self.L.sky_op_bytes(self.h, i, ctypes.byref(b)), self.h)
         return b.value
+
+    def op_io_bytes(self, i, with_raw=False):
+        """(bytes read, bytes written) of planned op i; a launch that computes a chain of ops reads the first op's and writes the last op's"""
+        r, w = ctypes.c_double(), ctypes.c_double()
+        check(self.L.sky_op_io_bytes(self.h, i, 1 if with_raw else 0, ctypes.byref(r), ctypes.byref(w)), self.h)
+        return r.value, w.value
 
     def stats(self):
         f, a, w, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
