@@ -80,6 +80,12 @@ def lib():
         raise SkyEyeNativeError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
             "The SkyEye engine has no CPU or PyTorch fallback.")
+    try:
+        # the process's HIP runtime must be the one torch brings (its bundled libamdhip64): loaded first, this library would pull in /opt/rocm's copy,
+        # torch's copy would initialise a second runtime and the devices / streams / pointers of the two would not be each other's
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, ip = ctypes.c_void_p, ctypes.c_int
     L.sky_abi_version.restype = ip
