@@ -241,14 +241,36 @@ def main():
         ex = [BoxExchange(B, 300, 7, dev, always_collective=force_ex) for _ in range(3)] if multi else None
         ag = {"ms": 0.0, "n": 0, "ev": []}
 
+        # the collective runs on a SIDE stream behind the step that filled its block, beside the next step's kernels: a rank that arrives late at
+        # the all-gather then delays the collective, not the other ranks' next forward pass.  A block is filled again two steps later (the pipelined
+        # loop alternates two blocks): that step waits for the block's last collective first (SKY_BENCH_GATHER_INLINE=1: on the step's own stream).
+        side = torch.cuda.Stream(device=dev) if multi and not os.environ.get("SKY_BENCH_GATHER_INLINE") else None
+        sent = {}                                                                   # exchange block -> event behind its last collective
+
         def gather(e):
             """the RCCL all-gather of one block, bracketed by events on the stream it is enqueued on (allgather_ms of the line)"""
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            res = e.gather()
-            e1.record()
+            if side is None:
+                e0.record()
+                res = e.gather()
+                e1.record()
+            else:
+                filled = torch.cuda.Event()
+                filled.record()                                                     # behind the replay that wrote the block
+                with torch.cuda.stream(side):
+                    side.wait_event(filled)
+                    e0.record(side)
+                    res = e.gather()
+                    e1.record(side)
+                sent[id(e)] = e1
             ag["ev"].append((e0, e1))
             return res
+
+        def before_refill(e):
+            """the step about to run writes block e again: behind the block's last collective"""
+            ev = sent.pop(id(e), None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
         def local_step():
             out = (ex[2].rows, ex[2].counts) if ex else None
@@ -263,6 +285,8 @@ def main():
             graph, held = capture_graph(local_step, warmup=2)                       # static shapes: one hipGraph replay per step
 
         def sync_step():                                                            # one batch, forward then its own NMS (the latency figure)
+            if multi:
+                before_refill(ex[2])
             if graph is not None:
                 graph.replay()
                 rows, counts = held
@@ -291,6 +315,8 @@ def main():
             def step():
                 p = state["k"] & 1
                 state["k"] += 1
+                if multi:
+                    before_refill(ex[1 - p])                                        # this step's NMS (of the previous batch) lands in block 1 - p
                 if graphs is not None:
                     graphs[p][0].replay()
                     res = graphs[p][1]
@@ -317,6 +343,7 @@ def main():
             def finish():
                 res = model.detect_nms_flush(parity=(state["k"] - 1) & 1)
                 if multi:
+                    before_refill(ex[2])
                     ex[2].rows.copy_(res[0]); ex[2].counts.copy_(res[1])            # (the flush outside the loop: once per leg)
                     res = gather(ex[2])
                 return res
