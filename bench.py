@@ -300,17 +300,27 @@ def main():
         if pipelined:
             # throughput form: step k = forward(batch k) beside NMS(batch k - 1) (two buffer sets, two graphs replayed alternately);
             # finish() = the last batch's NMS, inside the timed region: K steps do K forward passes and K + 1 NMS calls
-            def pipe_step(p):
-                # the boxes of the PREVIOUS batch (parity 1 - p) land in exchange block 1 - p
+            def pipe_step(p, blk=None):
+                # the boxes of the PREVIOUS batch (parity 1 - p) land in exchange block 1 - p (or in the block the caller names)
+                if blk is None and ex:
+                    blk = ex[1 - p]
                 return model.detect_nms_pipelined(x, a.conf, a.iou, max_detections=300, parity=p,
-                                                  out=(ex[1 - p].rows, ex[1 - p].counts) if ex else None)
+                                                  out=(blk.rows, blk.counts) if blk is not None else None)
             graphs = None if a.no_graph else [capture_graph(lambda p=p: pipe_step(p), warmup=2) for p in (0, 1)]
             # two steps (parity 0 then 1) as ONE replay where nothing happens between them on the host: one graph-launch gap per two batches
             pair = None
             npair = max(1, int(os.environ.get("SKY_BENCH_PAIRS", "2")))          # even / odd pairs per replay
             if graphs is not None and not multi and not os.environ.get("SKY_BENCH_NO_PAIR"):
                 pair = capture_graph(lambda: tuple(pipe_step(i & 1) for i in range(2 * npair)), warmup=1)
-            state = {"k": 0}
+            # N > 1: the same replays; every step of a replay writes its OWN exchange block, the collectives of a replay's blocks run behind it on
+            # the side stream, and two such graphs alternate so that a replay never waits for the collectives of the one before it
+            mpairs = None
+            if graphs is not None and multi and side is not None and not os.environ.get("SKY_BENCH_NO_PAIR"):
+                mpairs = []
+                for _g in range(2):
+                    blks = [BoxExchange(B, 300, 7, dev, always_collective=force_ex) for _ in range(2 * npair)]
+                    mpairs.append((capture_graph(lambda blks=blks: tuple(pipe_step(i & 1, blks[i]) for i in range(2 * npair)), warmup=1), blks))
+            state = {"k": 0, "g": 0}
 
             def step():
                 p = state["k"] & 1
@@ -335,6 +345,16 @@ def main():
                         res = pair[1][-1]
                         state["k"] += 2 * npair
                         n -= 2 * npair
+                    elif mpairs is not None and n >= 2 * npair and not (state["k"] & 1):
+                        (gr, _held), blks = mpairs[state["g"] & 1]
+                        state["g"] += 1
+                        for b in blks:
+                            before_refill(b)
+                        gr.replay()
+                        for b in blks:
+                            res = gather(b)                                         # one collective per step, in step order
+                        state["k"] += 2 * npair
+                        n -= 2 * npair
                     else:
                         res = step()
                         n -= 1
@@ -350,6 +370,7 @@ def main():
         else:
             step = sync_step
             pair = None
+            mpairs = None
             npair = 1
 
             def finish():
@@ -402,7 +423,7 @@ def main():
                       "what": "forward then its own NMS" + (" then the all-gather" if world > 1 else "") + ", one graph replay per batch (--no-pipeline)"}
             ag["ev"].clear()
         return dict(model=model, P=P, x=x, frames_np=frames_np, step=sync_step, graph=graph, dt=dt, counts=counts, pipelined=pipelined,
-                    steps_per_replay=2 * npair if (pipelined and pair is not None) else 1, strict=strict, allgather_ms=ag_ms, rank_fps=rank_fps)
+                    steps_per_replay=2 * npair if (pipelined and (pair is not None or mpairs is not None)) else 1, strict=strict, allgather_ms=ag_ms, rank_fps=rank_fps)
 
     def fence():
         if multi:
