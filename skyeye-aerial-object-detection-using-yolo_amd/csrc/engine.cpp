@@ -2196,7 +2196,7 @@ int sky_op_info(const sky_handle* h, int index, char* text, int text_len)
     if (op.kind == OP_CONV)
         snprintf(text, text_len, "conv %dx%d s%d %d->%d in %dx%dx%d out %dx%d ld %d/%d%s%s%s %s%d", op.ks, op.ks, op.stride, op.cin, op.cout,
                  op.in.B, op.in.H, op.in.W, op.Ho, op.Wo, op.in.ld, op.out.ld, op.res.valid() ? (op.in2_cin ? " +res in2" : " +res") : (op.in2_cin ? " in2" : ""), op.up2 ? " up2" : "",
-                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 3256 ? "gemm1x1/" : op.variant == 7128 ? "bneck" : op.variant == 7256 ? "bneck128x2/" : op.variant == 7257 ? "bneck128x2-fp8/" : op.variant == 7065 ? "bneck64x3/" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
+                 op.head ? " head" : "", op.variant >= 9000 ? "fused-into-previous" : op.variant >= 8500 ? "csp-stage-fused-" : op.variant >= 8000 ? "stem+stride2-fused-" : op.variant == 1628 ? "cv3+head/" : op.variant == 3256 ? "gemm1x1/" : op.variant == 7128 ? "bneck" : op.variant == 7256 ? "bneck128x2/" : op.variant == 7257 ? "bneck128x2-fp8/" : op.variant == 7065 ? "bneck64x3/" : op.variant == 7066 ? "bneck64x4-fp8/" : op.variant >= 7000 ? "halo-cv1+3x3-" : op.variant >= 6000 ? "halo-s2-" : op.variant >= 5000 ? "halo-narrow" : op.variant >= 4600 ? "deep3x3/" : op.variant >= 4000 ? "halo" : op.variant >= 3000 ? "ring" : op.variant >= 2000 ? "stream" : op.variant >= 1500 ? "head-stream" : "tile", op.variant % (op.variant >= 1500 && op.variant < 2000 ? 500 : 1000));
     else
         snprintf(text, text_len, "%s in %dx%dx%dx%d out C%d", names[op.kind], op.in.B, op.in.H, op.in.W, op.in.C, op.out.C);
     if (h->e.opts) {   // developer switches this plan was made under (PlanOpt bits, sky_kernels.h)

@@ -1214,7 +1214,8 @@ bool conv_accepts_raw(int dtype, const ConvArgs& a0)
 // the fused cv1 + 3x3 form (conv_halo_kernel CV1): bf16, 64 -> 64 -> 64 channels (one 128-byte chunk, one 64-channel N tile)
 static bool cv1_shape_ok(int dtype, ConvArgs& a)
 {
-    if (dtype == 2) return a.Cin == 128 && a.Cout == 128 && bneck128w8_shape_ok(a);      // fp8 engine: the 128-channel bottleneck only (k_bneck_w8.hip)
+    if (dtype == 2)                                          // fp8 engine: the 128- and 64-channel bottleneck kernels (k_bneck_w8.hip, k_bneck_w64f8.hip)
+        return (a.Cin == 128 && a.Cout == 128 && bneck128w8_shape_ok(a)) || (a.Cin == 64 && a.Cout == 64 && bneck64w8_shape_ok(a));
     if (dtype != 1 || (a.out_dt >= 0 && a.out_dt != 1)) return false;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.head || a.out_f32 || a.up2 || a.src_mode || a.f2_w) return false;
     if (a.Cin == 128 && a.Cout == 128) return bneck128w_shape_ok(a) || bneck128_shape_ok(a);      // the 128-channel bottleneck kernels (k_bneck_w.hip, k_bneck.hip)
@@ -1239,8 +1240,8 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a0, hipStream_t s, int* v
     if (a.c1_w) {       // planned as a fused bottleneck: there is no other kernel for this op
         if (!cv1_shape_ok(dtype, a)) return hipErrorInvalidValue;
         if (dtype == 2) {
-            const hipError_t e8 = launch_bneck128w8(a, s);
-            if (e8 == hipSuccess && variant) *variant = 7257;
+            const hipError_t e8 = a.Cin == 64 ? launch_bneck64w8(a, s) : launch_bneck128w8(a, s);
+            if (e8 == hipSuccess && variant) *variant = a.Cin == 64 ? 7066 : 7257;
             return e8 == hipErrorNotSupported ? hipErrorInvalidValue : e8;
         }
         if (a.Cin == 128) {

@@ -213,6 +213,9 @@ hipError_t launch_bneck128(const ConvArgs& a, hipStream_t s);
 // BottleneckBlock(64, 64), bf16, 8 x 16 tiles, three workgroups per CU (k_bneck_w64.hip)
 bool bneck64w_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck64w(const ConvArgs& a, hipStream_t s);
+// BottleneckBlock(64, 64) of the fp8 engine: 64-byte pixels, taps paired into 16x16x128 instructions (k_bneck_w64f8.hip)
+bool bneck64w8_shape_ok(const ConvArgs& a);
+hipError_t launch_bneck64w8(const ConvArgs& a, hipStream_t s);
 // the same bottleneck in the fp8 engine (k_bneck_w8.hip): 128 channels = one 128-byte chunk, 16x16x128 block-scaled instructions
 bool bneck128w8_shape_ok(const ConvArgs& a);
 hipError_t launch_bneck128w8(const ConvArgs& a, hipStream_t s);

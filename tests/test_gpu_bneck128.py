@@ -74,8 +74,8 @@ def test_bneck128_against_fp32_engine():
 # The two-launch form it is compared with keeps the fused plan's buffers (SKY_BNECK128=pair: y1 -> A -> B -> y1 through the scratch tensors, the hidden
 # tensor materialised where the fused plan has its scale carrier), so both plans calibrate to the same scales; the in-place unfused plan
 # (SKY_NO_BNECK128=1) shares ONE scale between the stages of a CSP block and is only close.
-def _run8(n, x, mode, shortcut=True):
-    m = load_seeded(M.CSPBlock(256, 256, num_blocks=n, shortcut=shortcut), 23).set_precision("fp8")
+def _run8(n, x, mode, shortcut=True, width=256):
+    m = load_seeded(M.CSPBlock(width, width, num_blocks=n, shortcut=shortcut), 23).set_precision("fp8")
     if mode == "pair":
         os.environ["SKY_BNECK128"] = "pair"
     if mode == "big":                             # the 16 x 16-tile form of the kernel (measured slower, kept as a switch)
@@ -128,3 +128,30 @@ def test_fp8_bneck128_without_shortcut_and_against_the_in_place_plan():
     ef = float((yf3.float() - ref).norm() / ref.norm()), float((yi.float() - ref).norm() / ref.norm())
     print("fp8 CSP(256, n=3) relative L2 against fp32: fused plan %.4f, in-place plan %.4f" % ef)
     assert ef[0] < 0.12 and ef[1] < 0.12, ef
+
+
+# BottleneckBlock(64, 64) of the fp8 engine (k_bneck_w64f8.hip): 64-byte pixels, the nine taps paired into four 16x16x128 instructions + one 16x16x32
+# pair exactly as the narrow halo kernel pairs its K-steps
+CASES64 = [(3, 2, 48, 48), (2, 1, 16, 16), (2, 2, 40, 56), (4, 1, 33, 47), (3, 8, 192, 192), (3, 2, 24, 100)]
+
+
+@pytest.mark.parametrize("case", CASES64, ids=["n%d_b%d_%dx%d" % c for c in CASES64])
+def test_fp8_bneck64_equals_two_launch_form(case):
+    n, B, H, W = case
+    x = torch.from_numpy(seeded_input("bk64f8.x.%d.%d" % (H, W), (B, 128, H, W), 3, -2.0, 2.0)).cuda()
+    yf, info_f, sc_f = _run8(n, x, "fused", width=128)
+    yp, info_p, sc_p = _run8(n, x, "pair", width=128)
+    assert sum("bneck64x4-fp8" in t for t in info_f) == n, info_f
+    assert not any("bneck64" in t for t in info_p) and len(info_p) == len(info_f) + n, info_p
+    assert len(sc_f) == len(sc_p) and all(a == b for a, b in zip(sc_f, sc_p)), "the two plans calibrated to different scales"
+    assert bool(torch.isfinite(yf).all()) and float(yf.abs().max()) > 0
+    assert torch.equal(yf, yp), f"{int((yf != yp).sum())} of {yf.numel()} values differ, max {float((yf - yp).abs().max())}"
+    yf2, _, _ = _run8(n, x, "fused", width=128)
+    assert torch.equal(yf, yf2)
+
+
+def test_fp8_bneck64_without_shortcut():
+    x = torch.from_numpy(seeded_input("bk64f8.ns", (2, 128, 40, 40), 7, -2.0, 2.0)).cuda()
+    yf, info_f, _ = _run8(2, x, "fused", shortcut=False, width=128)
+    yp, _, _ = _run8(2, x, "pair", shortcut=False, width=128)
+    assert sum("bneck64x4-fp8" in t for t in info_f) == 2 and torch.equal(yf, yp)

@@ -34,6 +34,8 @@ for k, v in agg.items():
         variant = 8564
     elif "bneck128w8" in k:
         variant = 7257
+    elif "bneck64w8" in k:
+        variant = 7066
     elif "bneck64w" in k:
         variant = 7065
     elif "bneck128w" in k:
